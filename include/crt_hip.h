@@ -1,0 +1,201 @@
+/*
+ * crt_hip.h -- C ABI of libcrt_hip.so, the MI355X (gfx950) drop-in for the reference's per-pixel
+ * render loop.  Plain C, plain pointers and sizes; no C++/torch types cross this boundary.
+ *
+ * R/ = /root/reference/DirectX-RayTracer/DirectX-RayTracer/.  The reference has no FFI: its seam is the
+ * C++ class DXRTRenderer (R/DXRTRenderer.h:74-94) plus the CRT* scene layer it owns.  Every entry point
+ * below names the reference member it stands in for; INTEGRATION.md shows the binding a maintainer adds.
+ *
+ * Conventions: every function returning int returns CRT_OK (0) or a CRT_E* code and records a message
+ * retrievable with crt_last_error().  The reference reports failure with assert()/ignored HRESULTs
+ * (R/DXRTRenderer.cpp:75,113,130,...); the error code replaces that.  A context is used from one host
+ * thread at a time (the reference is single threaded, R/DXRTApp.cpp:109-120).  The caller owns every host
+ * buffer it passes; the context owns all device memory.  There is NO CPU fallback: without a usable HIP
+ * device crt_create() fails with CRT_ENODEVICE.
+ */
+#ifndef CRT_HIP_H
+#define CRT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CRT_ABI_VERSION 1
+
+enum {
+    CRT_OK = 0,
+    CRT_EINVAL = 1,    /* bad argument */
+    CRT_ENODEVICE = 2, /* no HIP device / HIP runtime error at init */
+    CRT_EHIP = 3,      /* HIP runtime error */
+    CRT_ENOMEM = 4,
+    CRT_ESTATE = 5,    /* call order (e.g. render before upload) */
+    CRT_EIO = 6,       /* scene file */
+    CRT_EPARSE = 7
+};
+
+#define CRT_MISS 0xFFFFFFFFu
+/* shading modes: 0..6 are the reference's closest-hit modes (R/HLSL/ray_tracing_shaders.hlsl:78-169,
+ * UI names R/DXRTMainWindow.cpp:100-106; any value in 6..99 behaves as 6, like the shader's final else).
+ * >= 100 are extensions that do not exist in the reference. */
+#define CRT_MODE_RANDOM_TRIANGLE 0u
+#define CRT_MODE_OBJECT_CELLS 1u
+#define CRT_MODE_OBJECT_TRIANGLE 2u
+#define CRT_MODE_BARYCENTRIC 3u
+#define CRT_MODE_HEIGHT 4u
+#define CRT_MODE_DISTANCE 5u
+#define CRT_MODE_CHECKER 6u
+#define CRT_MODE_LAMBERT 100u /* Lambert + one shadow ray per light (BASELINE.json north_star) */
+
+/* ---- geometry handed over at upload: exactly what createVertexBuffers / createIndexBuffers memcpy ----
+ * (R/DXRTRenderer.cpp:391-392,411 and :314-315,334): float xyz stride 12, uint32 indices, mesh ordinal
+ * = InstanceID (R/DXRTRenderer.cpp:696). */
+typedef struct crt_mesh_view {
+    const float* xyz;      /* n_vertices * 3                                  (CRTMesh::getVertices) */
+    const uint32_t* idx;   /* n_triangles * 3                                 (CRTMesh::getIndices) */
+    const float* normals;  /* n_vertices * 3 or NULL                          (CRTMesh::getVertexNormals) */
+    uint32_t n_vertices;
+    uint32_t n_triangles;
+    int32_t material_index; /*                                                (CRTMesh::getMaterialIndex) */
+} crt_mesh_view;
+
+typedef struct crt_light { float pos[3]; float intensity; } crt_light;                 /* R/CRTLight.h:4-16 */
+typedef struct crt_material { float albedo[3]; uint32_t type; uint32_t smooth; float ior; } crt_material; /* R/CRTMaterial.h:4-36; type = CRTMaterialType */
+
+/* 64-byte BVH node and 48-byte leaf-ordered triangle/shading records as they sit in HBM */
+typedef struct crt_bvh_node {
+    float lx0, lx1, ly0, ly1, rx0, rx1, ry0, ry1, lz0, lz1, rz0, rz1;
+    int32_t left, right; /* >= 0 inner node index; < 0 leaf: ~ref = (first_tri << 3) | count */
+    int32_t pad0, pad1;
+} crt_bvh_node;
+typedef struct crt_bvh_tri { float v0[3]; uint32_t inst; float e1[3]; uint32_t prim; float e2[3]; uint32_t gid; } crt_bvh_tri;
+typedef struct crt_bvh_shade { float n0[3], n1[3], n2[3]; uint32_t material; uint32_t pad[2]; } crt_bvh_shade;
+
+typedef struct crt_frame_stats {
+    double kernel_ms;        /* HIP-event time of the render kernel(s) on the context's stream */
+    double total_ms;         /* wall time of the call (includes D2H copies when host outputs are requested) */
+    uint64_t rays_primary;   /* = pixels rendered by this call */
+    uint64_t rays_shadow;    /* counted only when counting is enabled, else 0 */
+    uint64_t nodes_visited;  /* idem: 64-byte node records fetched, summed over all rays */
+    uint64_t tris_tested;    /* idem: 48-byte triangle records fetched */
+} crt_frame_stats;
+
+typedef struct crt_ctx crt_ctx;
+
+/* ---------------------------------------------------------------------------------------------------
+ * Renderer: stands in for DXRTRenderer (R/DXRTRenderer.h:74-94)
+ * ------------------------------------------------------------------------------------------------- */
+
+/* DXRTRenderer::prepareForRendering minus window/swap chain (R/DXRTRenderer.cpp:44-62): bind to one HIP
+ * device (one process per GPU), create the stream and timing events. */
+int crt_create(crt_ctx** out, int device_id);
+void crt_destroy(crt_ctx* ctx);
+const char* crt_last_error(const crt_ctx* ctx); /* ctx may be NULL: last error of a failed crt_create */
+uint32_t crt_abi_version(void);
+
+/* createVertexBuffers + createIndexBuffers + createAccelerationStructures
+ * (R/DXRTRenderer.cpp:379-453, 302-376, 548-806): copies geometry, builds the BVH on the host (binned SAH)
+ * and uploads nodes / leaf-ordered triangles / shading records to HBM. The scene is immutable afterwards
+ * (the reference never refits either); a second call replaces it. */
+int crt_upload_scene(crt_ctx* ctx, const crt_mesh_view* meshes, uint32_t n_meshes,
+                     const crt_light* lights, uint32_t n_lights,
+                     const crt_material* materials, uint32_t n_materials);
+
+/* updateCameraCB (R/DXRTRenderer.cpp:248-270): position + 3x3 row-major rotation, dirWorld = R * dirCam */
+int crt_set_camera(crt_ctx* ctx, const float pos[3], const float rot3x3_rowmajor[9]);
+/* changeShadingMode (R/DXRTRenderer.cpp:1359-1363) */
+int crt_set_shading_mode(crt_ctx* ctx, uint32_t mode);
+/* miss colour; default (0,1,1) = the reference's miss shader (hlsl:72-76) */
+int crt_set_miss_color(crt_ctx* ctx, const float rgb[3]);
+/* when enabled the render kernels also count node/triangle fetches and shadow rays (slower variant) */
+int crt_set_counting(crt_ctx* ctx, int enabled);
+
+/* renderFrame (R/DXRTRenderer.cpp:1370-1408), synchronous like the reference (fence wait :521-527).
+ * Host outputs, any may be NULL: rgba8 w*h*4 (R8G8B8A8_UNORM, row-major, top-left origin), hit_inst / hit_prim
+ * w*h uint32 (CRT_MISS on miss), hit_t w*h float, rgb_f32 w*h*3 float (pre-quantisation colour). */
+int crt_render_frame(crt_ctx* ctx, uint32_t width, uint32_t height,
+                     uint8_t* rgba8, uint32_t* hit_inst, uint32_t* hit_prim, float* hit_t, float* rgb_f32,
+                     crt_frame_stats* stats);
+
+/* Same frame, outputs left in HBM: device pointers (any may be NULL except d_rgba8). Asynchronous on the
+ * context's stream unless stats != NULL (then it synchronises to read the timers). */
+int crt_render_frame_device(crt_ctx* ctx, uint32_t width, uint32_t height,
+                            void* d_rgba8, void* d_hit_inst, void* d_hit_prim, void* d_hit_t, void* d_rgb_f32,
+                            crt_frame_stats* stats);
+
+/* ---- tile-partitioned rendering for N GPUs (no reference counterpart) ----------
+ * The frame is cut into 16x16-pixel macro tiles, numbered row-major; macro tile k belongs to rank k % n_ranks.
+ * A rank renders its tiles into a rank-contiguous, tile-major staging buffer: slot j (= k / n_ranks) holds
+ * 256 RGBA8 pixels (row-major inside the tile; pixels outside the frame are left untouched).  All ranks use the
+ * same slot count crt_tile_slots() so the per-rank buffers can be gathered with one RCCL all-gather/gather. */
+uint32_t crt_tile_count(uint32_t width, uint32_t height);
+uint32_t crt_tile_slots(uint32_t width, uint32_t height, uint32_t n_ranks); /* ceil(tile_count / n_ranks) */
+int crt_render_tiles_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t rank, uint32_t n_ranks,
+                            void* d_staging_rgba8 /* slots*256*4 bytes */, crt_frame_stats* stats);
+/* De-interleave a gathered buffer (n_ranks * slots * 1024 bytes, rank-major) into a row-major frame. */
+int crt_untile_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_ranks,
+                      const void* d_gathered, void* d_rgba8_rowmajor);
+
+/* stream plumbing: use an external hipStream_t (e.g. torch's current stream); NULL restores the own stream */
+int crt_set_stream(crt_ctx* ctx, void* hip_stream);
+int crt_synchronize(crt_ctx* ctx);
+
+/* BVH introspection (tests, tooling): sizes, then copies of the host-side arrays uploaded to HBM */
+int crt_bvh_info(const crt_ctx* ctx, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* max_depth);
+int crt_bvh_export(const crt_ctx* ctx, crt_bvh_node* nodes, crt_bvh_tri* tris, crt_bvh_shade* shade);
+/* host-only BVH build, no device needed (used by crt_upload_scene; exposed for tests and tooling) */
+int crt_bvh_build_host(const crt_mesh_view* meshes, uint32_t n_meshes,
+                       crt_bvh_node** nodes, uint32_t* n_nodes,
+                       crt_bvh_tri** tris, crt_bvh_shade** shade, uint32_t* n_tris, uint32_t* max_depth);
+void crt_free(void* p);
+
+/* ---------------------------------------------------------------------------------------------------
+ * Scene layer: stands in for CRTScene / CRTSceneParser / CRTCamera (kept API surface, host only, no GPU)
+ * ------------------------------------------------------------------------------------------------- */
+typedef struct crt_scene crt_scene;
+
+/* CRTScene::CRTScene(file) -> CRTSceneParser::parseScene (R/CRTScene.cpp:7-15, R/CRTSceneParser.cpp:407-427).
+ * Accepts .crtscene (JSON) and, as an extension, .obj. Absent optional keys take defaults instead of the
+ * reference's undefined behaviour. */
+int crt_scene_load(const char* path, crt_scene** out, char* err, size_t err_len);
+/* empty scene to be filled programmatically */
+int crt_scene_new(crt_scene** out);
+void crt_scene_free(crt_scene* s);
+/* CRTMesh::addVertex/addIndex/setMaterialIndex + calculateVertexNormals (R/CRTMesh.cpp:6-24,66-94) */
+int crt_scene_add_mesh(crt_scene* s, const float* xyz, uint32_t n_vertices, const uint32_t* idx, uint32_t n_triangles,
+                       int32_t material_index);
+int crt_scene_add_light(crt_scene* s, const float pos[3], float intensity);
+int crt_scene_add_material(crt_scene* s, const crt_material* m);
+
+uint32_t crt_scene_mesh_count(const crt_scene* s);                               /* getObjects().size() */
+int crt_scene_mesh(const crt_scene* s, uint32_t i, crt_mesh_view* out);          /* views into scene-owned memory */
+uint32_t crt_scene_light_count(const crt_scene* s);                              /* getLights() */
+int crt_scene_light(const crt_scene* s, uint32_t i, crt_light* out);
+uint32_t crt_scene_material_count(const crt_scene* s);                           /* getMaterials() */
+int crt_scene_material(const crt_scene* s, uint32_t i, crt_material* out);
+uint32_t crt_scene_texture_count(const crt_scene* s);                            /* getTextures().size() */
+int crt_scene_settings(const crt_scene* s, uint32_t* width, uint32_t* height, float background_rgb[3]); /* getSettings() */
+
+/* CRTCamera (R/CRTCamera.h:5-32, .cpp:9-130) on the scene's camera */
+int crt_scene_camera_get(const crt_scene* s, float pos[3], float rot[9]);
+int crt_scene_camera_set(crt_scene* s, const float pos[3], const float rot[9]);
+int crt_scene_camera_rotate(crt_scene* s, float delta_yaw_deg, float delta_pitch_deg);
+int crt_scene_camera_zoom(crt_scene* s, float amount);
+int crt_scene_camera_move_forward(crt_scene* s, float distance);
+int crt_scene_camera_move_right(crt_scene* s, float distance);
+int crt_scene_camera_pan(crt_scene* s, float degrees);
+int crt_scene_camera_tilt(crt_scene* s, float degrees);
+int crt_scene_camera_roll(crt_scene* s, float degrees);
+int crt_scene_camera_pan_around_target(crt_scene* s, float degrees, const float target[3]);
+
+/* convenience: crt_upload_scene + crt_set_camera from a loaded scene (what DXRTRenderer::createScene +
+ * create*Buffers + createAccelerationStructures do with the CRTScene it owns, R/DXRTRenderer.cpp:243-246) */
+int crt_upload_scene_from(crt_ctx* ctx, const crt_scene* s);
+int crt_set_camera_from(crt_ctx* ctx, const crt_scene* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,732 @@
+/*
+ * crt_oracle.c -- CPU ORACLE.  TEST INFRASTRUCTURE, NOT PRODUCT CODE (see crt_oracle.h).
+ *
+ * Plain C11 restatement of the reference's per-pixel render loop
+ *   R/HLSL/ray_tracing_shaders.hlsl:21-169  (R/ = /root/reference/DirectX-RayTracer/DirectX-RayTracer/)
+ * plus a build-defined specification of what the reference leaves to the DXR driver
+ * (BVH build + traversal + ray/triangle test) and of the Lambert/shadow extension.
+ *
+ * Pinning status:
+ *   - scene layer the oracle is fed from: pinned by tests/golden/dragon_scene_layer.json, produced by
+ *     the reference's own CRT* sources compiled in place (oracle/Makefile, oracle/make_golden.py);
+ *   - rayGen / miss / closestHit colour functions: restated line by line from the HLSL (citations at
+ *     each function); the reference holds no golden image, so closed-form known answers are used;
+ *   - traversal / intersection / tie-break / sin() / Lambert: PARITY UNPINNED against the reference
+ *     (closed driver code, no fixtures); pinned internally by brute force (no BVH) == BVH.
+ *
+ * Arithmetic contract (mirrored exactly by the HIP kernels): IEEE-754 binary32, round to
+ * nearest even, no flush-to-zero, compiled with -ffp-contract=off; a multiply-add is fused only where
+ * fmaf()/fma() is written; division and sqrt correctly rounded; saturate uses fminf/fmaxf (IEEE minNum/maxNum: NaN -> 0); traversal/builder min/max are selects.
+ */
+#include "crt_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * constants
+ * ---------------------------------------------------------------------------------------------- */
+#define RAY_TMIN 0.001f   /* hlsl:51 */
+#define RAY_TMAX 10000.0f /* hlsl:52 */
+#define DIR_EPS 1e-20f    /* |d| below this is replaced by +-DIR_EPS for the slab reciprocal only */
+#define LEAF_MAX 4
+#define MAX_DEPTH 32      /* leaves at depth <= MAX_DEPTH  => traversal stack <= MAX_DEPTH entries */
+#define N_BINS 16
+#define C_TRAV 1.0f       /* SAH: cost of visiting an inner node, in triangle tests */
+#define SHADOW_BIAS 1e-3f
+#define FOUR_PI 12.566370614359172f
+
+/* ------------------------------------------------------------------------------------------------
+ * small math (explicit FMA placement is part of the contract)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { float x, y, z; } v3;
+
+static inline v3 v3_make(float x, float y, float z) { v3 r = { x, y, z }; return r; }
+static inline v3 v3_sub(v3 a, v3 b) { return v3_make(a.x - b.x, a.y - b.y, a.z - b.z); }
+static inline float v3_dot(v3 a, v3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+static inline v3 v3_cross(v3 a, v3 b)
+{
+    return v3_make(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+static inline v3 v3_normalize(v3 a)
+{
+    float inv = 1.0f / sqrtf(v3_dot(a, a));
+    return v3_make(a.x * inv, a.y * inv, a.z * inv);
+}
+/* min/max of the traversal and the builder: plain selects (x86 minss/maxss, GPU v_min/v_max agree with
+ * them for every non-NaN input; the slab test and the builder never see a NaN for finite scenes) */
+static inline float minf_(float a, float b) { return a < b ? a : b; }
+static inline float maxf_(float a, float b) { return a > b ? a : b; }
+static inline float fracf_(float x) { return x - floorf(x); }
+static inline float saturatef_(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+static inline float lerpf_(float a, float b, float t) { return a + t * (b - a); }
+
+/* sin() with a fixed operation sequence shared with the kernel: double range reduction by 2*pi
+ * (two-term Cody-Waite with fma), odd Taylor polynomial to r^23 on [-pi, pi] in double (Horner, fma),
+ * rounded once to float.  |error| < 1 ulp(float) for every finite float x up to 2^40. */
+float oracle_sinf(float x)
+{
+    const double INV_2PI = 0x1.45f306dc9c883p-3;
+    const double TWO_PI_HI = 0x1.921fb54442d18p+2;
+    const double TWO_PI_LO = 0x1.1a62633145c07p-52;
+    double xd = (double)x;
+    double k = rint(xd * INV_2PI);
+    double r = fma(-k, TWO_PI_HI, xd);
+    r = fma(-k, TWO_PI_LO, r);
+    double r2 = r * r;
+    double p = -0x1.761b41316381ap-75;         /* -1/23! */
+    p = fma(p, r2, 0x1.71b8ef6dcf572p-66);     /* +1/21! */
+    p = fma(p, r2, -0x1.2f49b46814157p-57);    /* -1/19! */
+    p = fma(p, r2, 0x1.952c77030ad4ap-49);     /* +1/17! */
+    p = fma(p, r2, -0x1.ae7f3e733b81fp-41);    /* -1/15! */
+    p = fma(p, r2, 0x1.6124613a86d09p-33);     /* +1/13! */
+    p = fma(p, r2, -0x1.ae64567f544e4p-26);    /* -1/11! */
+    p = fma(p, r2, 0x1.71de3a556c734p-19);     /* +1/9!  */
+    p = fma(p, r2, -0x1.a01a01a01a01ap-13);    /* -1/7!  */
+    p = fma(p, r2, 0x1.1111111111111p-7);      /* +1/5!  */
+    p = fma(p, r2, -0x1.5555555555555p-3);     /* -1/3!  */
+    p = p * r2;
+    return (float)fma(p, r, r);
+}
+
+/* float4 -> R8G8B8A8_UNORM channel (R/DXRTRenderer.cpp:921-946): saturate, scale, round half up */
+uint8_t oracle_unorm8(float c)
+{
+    float s = saturatef_(c); /* NaN -> 0 */
+    return (uint8_t)(s * 255.0f + 0.5f);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * scene
+ * ---------------------------------------------------------------------------------------------- */
+struct oracle_scene {
+    oracle_node* nodes;
+    uint32_t n_nodes;
+    oracle_tri* tris;     /* leaf order */
+    oracle_shade* shade;  /* leaf order */
+    uint32_t n_tris;
+    uint32_t max_depth;
+    oracle_light* lights;
+    uint32_t n_lights;
+    oracle_material* mats;
+    uint32_t n_mats;
+};
+
+typedef struct { float mn[3], mx[3]; } aabb;
+
+static inline void aabb_empty(aabb* b)
+{
+    for (int a = 0; a < 3; a++) { b->mn[a] = INFINITY; b->mx[a] = -INFINITY; }
+}
+static inline void aabb_grow(aabb* b, const aabb* o)
+{
+    for (int a = 0; a < 3; a++) { b->mn[a] = minf_(b->mn[a], o->mn[a]); b->mx[a] = maxf_(b->mx[a], o->mx[a]); }
+}
+static inline float aabb_half_area(const aabb* b)
+{
+    float dx = b->mx[0] - b->mn[0], dy = b->mx[1] - b->mn[1], dz = b->mx[2] - b->mn[2];
+    return (dx * dy + dy * dz) + dz * dx;
+}
+
+typedef struct {
+    const aabb* pbox;    /* per input triangle */
+    const float* pcent;  /* per input triangle, 3 floats */
+    uint32_t* order;     /* permutation being partitioned */
+    uint32_t* tmp;
+    oracle_node* nodes;
+    uint32_t n_nodes;
+    uint32_t max_depth;
+} builder;
+
+static inline int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | count); }
+
+/* Deterministic binned-SAH build of order[first, first+count). Returns the child reference and the
+ * exact bounds of the range. Spec (DESIGN.md "BVH build"): 16 bins per axis over the centroid bounds,
+ * candidates scanned axis 0..2, plane 1..15, strict '<' keeps the first minimum; stable partition;
+ * ranges of <= LEAF_MAX triangles are split only if that lowers the SAH cost; a split that would make
+ * the depth bound unreachable, or no valid split, falls back to the median of the current order. */
+static int32_t build_range(builder* B, uint32_t first, uint32_t count, uint32_t depth, aabb* out_box)
+{
+    aabb box, cbox;
+    aabb_empty(&box);
+    aabb_empty(&cbox);
+    for (uint32_t i = first; i < first + count; i++) {
+        uint32_t p = B->order[i];
+        aabb_grow(&box, &B->pbox[p]);
+        for (int a = 0; a < 3; a++) {
+            float c = B->pcent[3 * p + a];
+            cbox.mn[a] = minf_(cbox.mn[a], c);
+            cbox.mx[a] = maxf_(cbox.mx[a], c);
+        }
+    }
+    *out_box = box;
+    if (depth > B->max_depth) B->max_depth = depth;
+    if (count <= 1 || depth >= MAX_DEPTH) return leaf_ref(first, count);
+
+    /* --- best binned split ------------------------------------------------------------------- */
+    float best_cost = INFINITY;
+    int best_axis = -1, best_plane = 0;
+    float best_scale = 0.0f;
+    for (int a = 0; a < 3; a++) {
+        float ext = cbox.mx[a] - cbox.mn[a];
+        if (!(ext > 0.0f)) continue;
+        float scale = (float)N_BINS / ext;
+        aabb bbox[N_BINS];
+        uint32_t bcnt[N_BINS];
+        for (int b = 0; b < N_BINS; b++) { aabb_empty(&bbox[b]); bcnt[b] = 0; }
+        for (uint32_t i = first; i < first + count; i++) {
+            uint32_t p = B->order[i];
+            int b = (int)((B->pcent[3 * p + a] - cbox.mn[a]) * scale);
+            if (b > N_BINS - 1) b = N_BINS - 1;
+            bcnt[b]++;
+            aabb_grow(&bbox[b], &B->pbox[p]);
+        }
+        /* suffix boxes */
+        aabb rbox[N_BINS];
+        uint32_t rcnt[N_BINS];
+        aabb acc;
+        aabb_empty(&acc);
+        uint32_t n = 0;
+        for (int b = N_BINS - 1; b >= 1; b--) {
+            aabb_grow(&acc, &bbox[b]);
+            n += bcnt[b];
+            rbox[b] = acc;
+            rcnt[b] = n;
+        }
+        aabb_empty(&acc);
+        n = 0;
+        for (int s = 1; s < N_BINS; s++) { /* plane between bin s-1 and bin s */
+            aabb_grow(&acc, &bbox[s - 1]);
+            n += bcnt[s - 1];
+            if (n == 0 || rcnt[s] == 0) continue;
+            float cost = aabb_half_area(&acc) * (float)n + aabb_half_area(&rbox[s]) * (float)rcnt[s];
+            if (cost < best_cost) { best_cost = cost; best_axis = a; best_plane = s; best_scale = scale; }
+        }
+    }
+
+    float area = aabb_half_area(&box);
+    if (count <= LEAF_MAX) {
+        /* leaf unless splitting is cheaper: C_TRAV*A + best < count*A */
+        if (best_axis < 0 || !(C_TRAV * area + best_cost < (float)count * area)) return leaf_ref(first, count);
+    }
+
+    uint32_t n_left = 0;
+    if (best_axis >= 0) {
+        /* stable partition by bin < plane */
+        uint32_t nl = 0, nr = 0;
+        for (uint32_t i = first; i < first + count; i++) {
+            uint32_t p = B->order[i];
+            int b = (int)((B->pcent[3 * p + best_axis] - cbox.mn[best_axis]) * best_scale);
+            if (b > N_BINS - 1) b = N_BINS - 1;
+            if (b < best_plane) B->order[first + nl++] = p; /* nl <= i - first: never overtakes the read */
+            else B->tmp[nr++] = p;
+        }
+        memcpy(&B->order[first + nl], B->tmp, nr * sizeof(uint32_t));
+        n_left = nl;
+        /* depth bound: each side must still fit below MAX_DEPTH with median splits */
+        uint64_t cap = (uint64_t)LEAF_MAX << (MAX_DEPTH - depth - 1);
+        uint32_t big = nl > nr ? nl : nr;
+        if ((uint64_t)big > cap) n_left = 0; /* order stays partitioned (still deterministic); median below */
+    }
+    if (n_left == 0) n_left = count / 2;
+
+    uint32_t me = B->n_nodes++;
+    aabb lb, rb;
+    int32_t l = build_range(B, first, n_left, depth + 1, &lb);
+    int32_t r = build_range(B, first + n_left, count - n_left, depth + 1, &rb);
+    oracle_node* N = &B->nodes[me];
+    N->lx0 = lb.mn[0]; N->lx1 = lb.mx[0]; N->ly0 = lb.mn[1]; N->ly1 = lb.mx[1]; N->lz0 = lb.mn[2]; N->lz1 = lb.mx[2];
+    N->rx0 = rb.mn[0]; N->rx1 = rb.mx[0]; N->ry0 = rb.mn[1]; N->ry1 = rb.mx[1]; N->rz0 = rb.mn[2]; N->rz1 = rb.mx[2];
+    N->left = l; N->right = r; N->pad0 = 0; N->pad1 = 0;
+    return (int32_t)me;
+}
+
+oracle_scene* oracle_scene_create(const oracle_mesh* meshes, uint32_t n_meshes,
+                                  const oracle_light* lights, uint32_t n_lights,
+                                  const oracle_material* mats, uint32_t n_mats)
+{
+    oracle_scene* s = (oracle_scene*)calloc(1, sizeof(*s));
+    if (!s) return NULL;
+    uint64_t total = 0;
+    for (uint32_t m = 0; m < n_meshes; m++) total += meshes[m].n_triangles;
+    if (total >= (1u << 28)) { free(s); return NULL; }
+    uint32_t n = (uint32_t)total;
+    s->n_tris = n;
+    s->n_lights = n_lights;
+    s->n_mats = n_mats;
+    s->lights = (oracle_light*)malloc(sizeof(oracle_light) * (n_lights ? n_lights : 1));
+    s->mats = (oracle_material*)malloc(sizeof(oracle_material) * (n_mats ? n_mats : 1));
+    if (n_lights) memcpy(s->lights, lights, sizeof(oracle_light) * n_lights);
+    if (n_mats) memcpy(s->mats, mats, sizeof(oracle_material) * n_mats);
+
+    /* flatten in input order: gid = running triangle ordinal over meshes */
+    oracle_tri* in_tri = (oracle_tri*)malloc(sizeof(oracle_tri) * (n ? n : 1));
+    oracle_shade* in_sh = (oracle_shade*)malloc(sizeof(oracle_shade) * (n ? n : 1));
+    aabb* pbox = (aabb*)malloc(sizeof(aabb) * (n ? n : 1));
+    float* pcent = (float*)malloc(sizeof(float) * 3 * (n ? n : 1));
+    uint32_t g = 0;
+    for (uint32_t m = 0; m < n_meshes; m++) {
+        const oracle_mesh* M = &meshes[m];
+        for (uint32_t t = 0; t < M->n_triangles; t++, g++) {
+            const uint32_t i0 = M->idx[3 * t], i1 = M->idx[3 * t + 1], i2 = M->idx[3 * t + 2];
+            const float* a = &M->xyz[3 * i0];
+            const float* b = &M->xyz[3 * i1];
+            const float* c = &M->xyz[3 * i2];
+            oracle_tri* T = &in_tri[g];
+            for (int k = 0; k < 3; k++) {
+                T->v0[k] = a[k];
+                T->e1[k] = b[k] - a[k];
+                T->e2[k] = c[k] - a[k];
+                pbox[g].mn[k] = minf_(minf_(a[k], b[k]), c[k]);
+                pbox[g].mx[k] = maxf_(maxf_(a[k], b[k]), c[k]);
+                pcent[3 * g + k] = (pbox[g].mn[k] + pbox[g].mx[k]) * 0.5f;
+            }
+            T->inst = m; T->prim = t; T->gid = g;
+            oracle_shade* S = &in_sh[g];
+            memset(S, 0, sizeof(*S));
+            S->material = (uint32_t)M->material_index;
+            if (M->normals) {
+                memcpy(S->n0, &M->normals[3 * i0], 12);
+                memcpy(S->n1, &M->normals[3 * i1], 12);
+                memcpy(S->n2, &M->normals[3 * i2], 12);
+            }
+        }
+    }
+
+    builder B;
+    B.pbox = pbox; B.pcent = pcent;
+    B.order = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+    B.tmp = (uint32_t*)malloc(sizeof(uint32_t) * (n ? n : 1));
+    B.nodes = (oracle_node*)calloc(n ? n : 1, sizeof(oracle_node)); /* <= n-1 inner nodes, +1 for tiny scenes */
+    B.n_nodes = 0; B.max_depth = 0;
+    for (uint32_t i = 0; i < n; i++) B.order[i] = i;
+
+    if (n > 0) {
+        aabb rootbox;
+        int32_t root = build_range(&B, 0, n, 0, &rootbox);
+        if (root < 0) {
+            /* whole scene is one leaf: wrap it so that node 0 exists; right child = empty leaf, same box */
+            oracle_node* N = &B.nodes[0];
+            B.n_nodes = 1;
+            N->lx0 = N->rx0 = rootbox.mn[0]; N->lx1 = N->rx1 = rootbox.mx[0];
+            N->ly0 = N->ry0 = rootbox.mn[1]; N->ly1 = N->ry1 = rootbox.mx[1];
+            N->lz0 = N->rz0 = rootbox.mn[2]; N->lz1 = N->rz1 = rootbox.mx[2];
+            N->left = root; N->right = leaf_ref(0, 0); N->pad0 = N->pad1 = 0;
+        }
+    }
+    s->nodes = B.nodes;
+    s->n_nodes = B.n_nodes;
+    s->max_depth = B.max_depth;
+    s->tris = (oracle_tri*)malloc(sizeof(oracle_tri) * (n ? n : 1));
+    s->shade = (oracle_shade*)malloc(sizeof(oracle_shade) * (n ? n : 1));
+    for (uint32_t i = 0; i < n; i++) { s->tris[i] = in_tri[B.order[i]]; s->shade[i] = in_sh[B.order[i]]; }
+    free(B.order); free(B.tmp); free(in_tri); free(in_sh); free(pbox); free(pcent);
+    return s;
+}
+
+void oracle_scene_destroy(oracle_scene* s)
+{
+    if (!s) return;
+    free(s->nodes); free(s->tris); free(s->shade); free(s->lights); free(s->mats);
+    free(s);
+}
+
+int oracle_scene_set_bvh(oracle_scene* s, const oracle_node* nodes, uint32_t n_nodes,
+                         const oracle_tri* tris, const oracle_shade* shade, uint32_t n_tris)
+{
+    if (!s) return 1;
+    free(s->nodes); free(s->tris); free(s->shade);
+    s->nodes = (oracle_node*)malloc(sizeof(oracle_node) * (n_nodes ? n_nodes : 1));
+    s->tris = (oracle_tri*)malloc(sizeof(oracle_tri) * (n_tris ? n_tris : 1));
+    s->shade = (oracle_shade*)calloc(n_tris ? n_tris : 1, sizeof(oracle_shade));
+    memcpy(s->nodes, nodes, sizeof(oracle_node) * n_nodes);
+    memcpy(s->tris, tris, sizeof(oracle_tri) * n_tris);
+    if (shade) memcpy(s->shade, shade, sizeof(oracle_shade) * n_tris);
+    s->n_nodes = n_nodes; s->n_tris = n_tris;
+    return 0;
+}
+
+uint32_t oracle_scene_node_count(const oracle_scene* s) { return s->n_nodes; }
+uint32_t oracle_scene_tri_count(const oracle_scene* s) { return s->n_tris; }
+const oracle_node* oracle_scene_nodes(const oracle_scene* s) { return s->nodes; }
+const oracle_tri* oracle_scene_tris(const oracle_scene* s) { return s->tris; }
+const oracle_shade* oracle_scene_shade(const oracle_scene* s) { return s->shade; }
+uint32_t oracle_scene_max_depth(const oracle_scene* s) { return s->max_depth; }
+
+/* ------------------------------------------------------------------------------------------------
+ * rays
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+    v3 o, d;
+    v3 idir, noid; /* 1/d (clamped) and -(o * idir) for the fma slab test */
+} ray;
+
+static inline float safe_rcp_dir(float d)
+{
+    float ds = (fabsf(d) < DIR_EPS) ? copysignf(DIR_EPS, d) : d;
+    return 1.0f / ds;
+}
+
+static inline void ray_setup(ray* r, v3 o, v3 d)
+{
+    r->o = o; r->d = d;
+    r->idir = v3_make(safe_rcp_dir(d.x), safe_rcp_dir(d.y), safe_rcp_dir(d.z));
+    r->noid = v3_make(-(o.x * r->idir.x), -(o.y * r->idir.y), -(o.z * r->idir.z));
+}
+
+typedef struct { float t, u, v; uint32_t tri; /* leaf-order index */ uint32_t gid; int hit; } hit_rec;
+
+typedef struct { uint64_t nodes, tris; } trav_count;
+
+/* Moeller-Trumbore, two sided (no culling: R/DXRTRenderer.cpp:590,697-699 set no cull flags).
+ * u = weight of v1, v = weight of v2 (DXR barycentrics.x / .y, hlsl:127-131).  Rejections are written
+ * as positive-form compares so that NaN/inf (det == 0) reject without a separate test. */
+static inline int tri_test(const ray* r, const oracle_tri* T, float tmin, float* t, float* u, float* v)
+{
+    v3 e1 = v3_make(T->e1[0], T->e1[1], T->e1[2]);
+    v3 e2 = v3_make(T->e2[0], T->e2[1], T->e2[2]);
+    v3 p = v3_cross(r->d, e2);
+    float det = v3_dot(e1, p);
+    float inv = 1.0f / det;
+    v3 s = v3_sub(r->o, v3_make(T->v0[0], T->v0[1], T->v0[2]));
+    float uu = v3_dot(s, p) * inv;
+    v3 q = v3_cross(s, e1);
+    float vv = v3_dot(r->d, q) * inv;
+    float tt = v3_dot(e2, q) * inv;
+    *t = tt; *u = uu; *v = vv;
+    return (uu >= 0.0f) & (vv >= 0.0f) & (uu + vv <= 1.0f) & (tt > tmin);
+}
+
+static inline int box_test(float x0, float x1, float y0, float y1, float z0, float z1, const ray* r,
+                           float tmin, float tmax, float* tnear)
+{
+    float ax = fmaf(x0, r->idir.x, r->noid.x), bx = fmaf(x1, r->idir.x, r->noid.x);
+    float ay = fmaf(y0, r->idir.y, r->noid.y), by = fmaf(y1, r->idir.y, r->noid.y);
+    float az = fmaf(z0, r->idir.z, r->noid.z), bz = fmaf(z1, r->idir.z, r->noid.z);
+    float tn = maxf_(maxf_(minf_(ax, bx), minf_(ay, by)), maxf_(minf_(az, bz), tmin));
+    float tf = minf_(minf_(maxf_(ax, bx), maxf_(ay, by)), minf_(maxf_(az, bz), tmax));
+    *tnear = tn;
+    return tn <= tf;
+}
+
+/* closest hit in (tmin, tmax); equal t resolved towards the lower global triangle ordinal */
+static void trace_closest(const oracle_scene* s, const ray* r, float tmin, float tmax, hit_rec* h, trav_count* c)
+{
+    h->t = tmax; h->u = 0.0f; h->v = 0.0f; h->tri = 0; h->gid = 0; h->hit = 0;
+    if (s->n_nodes == 0) return;
+    int32_t stack[MAX_DEPTH + 1];
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const oracle_node* N = &s->nodes[cur];
+            c->nodes++;
+            float tnl, tnr;
+            int hl = box_test(N->lx0, N->lx1, N->ly0, N->ly1, N->lz0, N->lz1, r, tmin, h->t, &tnl);
+            int hr = box_test(N->rx0, N->rx1, N->ry0, N->ry1, N->rz0, N->rz1, r, tmin, h->t, &tnr);
+            if (hl & hr) {
+                int right_first = tnr < tnl;
+                stack[sp++] = right_first ? N->left : N->right;
+                cur = right_first ? N->right : N->left;
+                continue;
+            }
+            if (hl) { cur = N->left; continue; }
+            if (hr) { cur = N->right; continue; }
+        } else {
+            uint32_t code = (uint32_t)~cur;
+            uint32_t first = code >> 3, cnt = code & 7u;
+            for (uint32_t i = first; i < first + cnt; i++) {
+                const oracle_tri* T = &s->tris[i];
+                float t, u, v;
+                c->tris++;
+                if (tri_test(r, T, tmin, &t, &u, &v)) {
+                    if ((t < h->t) | ((t == h->t) & (T->gid < h->gid))) {
+                        h->t = t; h->u = u; h->v = v; h->tri = i; h->gid = T->gid; h->hit = 1;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+}
+
+/* any hit in (tmin, tmax): order independent */
+static int trace_any(const oracle_scene* s, const ray* r, float tmin, float tmax, trav_count* c)
+{
+    if (s->n_nodes == 0) return 0;
+    int32_t stack[MAX_DEPTH + 1];
+    int sp = 0;
+    int32_t cur = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const oracle_node* N = &s->nodes[cur];
+            c->nodes++;
+            float tnl, tnr;
+            int hl = box_test(N->lx0, N->lx1, N->ly0, N->ly1, N->lz0, N->lz1, r, tmin, tmax, &tnl);
+            int hr = box_test(N->rx0, N->rx1, N->ry0, N->ry1, N->rz0, N->rz1, r, tmin, tmax, &tnr);
+            if (hl & hr) {
+                int right_first = tnr < tnl;
+                stack[sp++] = right_first ? N->left : N->right;
+                cur = right_first ? N->right : N->left;
+                continue;
+            }
+            if (hl) { cur = N->left; continue; }
+            if (hr) { cur = N->right; continue; }
+        } else {
+            uint32_t code = (uint32_t)~cur;
+            uint32_t first = code >> 3, cnt = code & 7u;
+            for (uint32_t i = first; i < first + cnt; i++) {
+                float t, u, v;
+                c->tris++;
+                if (tri_test(r, &s->tris[i], tmin, &t, &u, &v) & (t < tmax)) return 1;
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return 0;
+}
+
+static void brute_closest(const oracle_scene* s, const ray* r, float tmin, float tmax, hit_rec* h, trav_count* c)
+{
+    h->t = tmax; h->u = 0.0f; h->v = 0.0f; h->tri = 0; h->gid = 0; h->hit = 0;
+    for (uint32_t i = 0; i < s->n_tris; i++) {
+        const oracle_tri* T = &s->tris[i];
+        float t, u, v;
+        c->tris++;
+        if (tri_test(r, T, tmin, &t, &u, &v)) {
+            if ((t < h->t) | ((t == h->t) & (T->gid < h->gid))) {
+                h->t = t; h->u = u; h->v = v; h->tri = i; h->gid = T->gid; h->hit = 1;
+            }
+        }
+    }
+}
+
+static int brute_any(const oracle_scene* s, const ray* r, float tmin, float tmax, trav_count* c)
+{
+    for (uint32_t i = 0; i < s->n_tris; i++) {
+        float t, u, v;
+        c->tris++;
+        if (tri_test(r, &s->tris[i], tmin, &t, &u, &v) & (t < tmax)) return 1;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * rayGen (hlsl:21-55).  The reference hard-codes width=1920,height=1080 (hlsl:24-25); here they are
+ * parameters, used in the same float expressions.
+ * ---------------------------------------------------------------------------------------------- */
+static inline v3 ray_dir(const float rot[9], uint32_t px, uint32_t py, float width, float height)
+{
+    float x = (float)px, y = (float)py;
+    x += 0.5f; y += 0.5f;            /* hlsl:35-36 */
+    x /= width; y /= height;         /* hlsl:38-39 */
+    x = (2.0f * x) - 1.0f;           /* hlsl:41 */
+    y = 1.0f - (2.0f * y);           /* hlsl:42 */
+    x *= width / height;             /* hlsl:44 */
+    v3 dc = v3_normalize(v3_make(x, y, -1.0f));                       /* hlsl:46 */
+    /* mul(cameraRotation, v): column vector, out_i = sum_j M[i][j] v_j   (hlsl:47, cpp:259-264) */
+    v3 dw = v3_make(v3_dot(v3_make(rot[0], rot[1], rot[2]), dc),
+                    v3_dot(v3_make(rot[3], rot[4], rot[5]), dc),
+                    v3_dot(v3_make(rot[6], rot[7], rot[8]), dc));
+    return v3_normalize(dw);
+}
+
+void oracle_ray_dir(const float rot[9], uint32_t px, uint32_t py, uint32_t w, uint32_t h, float out_dir[3])
+{
+    v3 d = ray_dir(rot, px, py, (float)w, (float)h);
+    out_dir[0] = d.x; out_dir[1] = d.y; out_dir[2] = d.z;
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * closestHit colour functions (hlsl:78-169)
+ * ---------------------------------------------------------------------------------------------- */
+static inline float hash_sin(float x, float k) { return fracf_(oracle_sinf(x) * k); }
+
+static inline v3 object_base_colour(uint32_t inst) /* hlsl:97-101, 117-121 */
+{
+    float f = (float)inst;
+    return v3_make(hash_sin(f * 12.9898f, 43758.5453f), hash_sin(f * 78.233f, 12345.6789f),
+                   hash_sin(f * 39.425f, 34567.8901f));
+}
+
+static v3 shade_debug(uint32_t mode, uint32_t inst, uint32_t prim, float t, float u, float v, v3 o, v3 d)
+{
+    v3 wp = v3_make(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t); /* WorldRayOrigin + WorldRayDirection * RayTCurrent */
+    if (mode == 0) { /* hlsl:84-91 */
+        float f = (float)prim;
+        return v3_make(hash_sin(f * 12.9898f, 43758.5453f), hash_sin(f * 78.233f, 43758.5453f),
+                       hash_sin(f * 45.164f, 43758.5453f));
+    }
+    if (mode == 1) { /* hlsl:93-112 */
+        v3 base = object_base_colour(inst);
+        int32_t cx = (int32_t)floorf(wp.x / 2.0f), cy = (int32_t)floorf(wp.y / 2.0f), cz = (int32_t)floorf(wp.z / 2.0f);
+        uint32_t hash = ((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u) ^ ((uint32_t)cz * 83492791u);
+        float variation = hash_sin((float)hash * 12.9898f, 43758.5453f);
+        return v3_make(lerpf_(base.x * 0.7f, base.x * 1.3f, variation), lerpf_(base.y * 0.7f, base.y * 1.3f, variation),
+                       lerpf_(base.z * 0.7f, base.z * 1.3f, variation));
+    }
+    if (mode == 2) { /* hlsl:113-124 */
+        v3 base = object_base_colour(inst);
+        float shade = hash_sin((float)prim * 12.9898f, 43758.5453f);
+        float k = lerpf_(0.6f, 1.0f, shade);
+        return v3_make(base.x * k, base.y * k, base.z * k);
+    }
+    if (mode == 3) /* hlsl:125-134 */
+        return v3_make(1.0f - u - v, u, v);
+    if (mode == 4) { /* hlsl:135-147 */
+        float h = saturatef_((wp.y + 10.0f) / 20.0f);
+        return v3_make(lerpf_(0.1f, 0.9f, h), lerpf_(0.2f, 0.9f, h), lerpf_(0.6f, 0.9f, h));
+    }
+    if (mode == 5) { /* hlsl:148-154 */
+        float c = saturatef_(t * 0.05f);
+        return v3_make(c, c, c);
+    }
+    { /* hlsl:155-166 */
+        int32_t checker = ((int32_t)floorf(wp.x) ^ (int32_t)floorf(wp.z)) & 1;
+        float c = checker ? 0.9f : 0.2f;
+        return v3_make(c, c, c);
+    }
+}
+
+void oracle_shade_mode(uint32_t mode, uint32_t inst, uint32_t prim, float t, float u, float v,
+                       const float o[3], const float d[3], float out_rgb[3])
+{
+    v3 c = shade_debug(mode, inst, prim, t, u, v, v3_make(o[0], o[1], o[2]), v3_make(d[0], d[1], d[2]));
+    out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z;
+}
+
+int oracle_intersect_tri(const float o[3], const float d[3], const float v0[3], const float v1[3],
+                         const float v2[3], float tmin, float tmax, float* t, float* u, float* v)
+{
+    ray r;
+    oracle_tri T;
+    ray_setup(&r, v3_make(o[0], o[1], o[2]), v3_make(d[0], d[1], d[2]));
+    for (int k = 0; k < 3; k++) { T.v0[k] = v0[k]; T.e1[k] = v1[k] - v0[k]; T.e2[k] = v2[k] - v0[k]; }
+    T.inst = T.prim = T.gid = 0;
+    return tri_test(&r, &T, tmin, t, u, v) & (*t < tmax);
+}
+
+/* Lambert + one shadow ray per light (mode 100). NOT IN THE REFERENCE: the reference parses lights and
+ * materials (R/CRTLight.h:4-16, R/CRTMaterial.h:4-36) but never evaluates them; this is the build's
+ * specification of BASELINE.json's "Lambert ... + shadow rays" (SURVEY.md section 8 row a13). */
+static v3 shade_lambert(const oracle_scene* s, const ray* r, const hit_rec* h, int brute, trav_count* c, uint64_t* n_shadow)
+{
+    const oracle_tri* T = &s->tris[h->tri];
+    const oracle_shade* S = &s->shade[h->tri];
+    v3 P = v3_make(r->o.x + r->d.x * h->t, r->o.y + r->d.y * h->t, r->o.z + r->d.z * h->t);
+    v3 albedo = v3_make(1.0f, 1.0f, 1.0f);
+    int smooth = 0;
+    if (S->material < s->n_mats) {
+        const oracle_material* M = &s->mats[S->material];
+        albedo = v3_make(M->albedo[0], M->albedo[1], M->albedo[2]);
+        smooth = M->smooth != 0;
+    }
+    v3 N = v3_cross(v3_make(T->e1[0], T->e1[1], T->e1[2]), v3_make(T->e2[0], T->e2[1], T->e2[2]));
+    if (smooth) {
+        float w = 1.0f - h->u - h->v;
+        v3 Ns = v3_make(fmaf(S->n2[0], h->v, fmaf(S->n1[0], h->u, S->n0[0] * w)),
+                        fmaf(S->n2[1], h->v, fmaf(S->n1[1], h->u, S->n0[1] * w)),
+                        fmaf(S->n2[2], h->v, fmaf(S->n1[2], h->u, S->n0[2] * w)));
+        if (v3_dot(Ns, Ns) > 0.0f) N = Ns; /* zero / missing normals (NaN compares false) -> face normal */
+    }
+    N = v3_normalize(N);
+    if (v3_dot(N, r->d) > 0.0f) N = v3_make(-N.x, -N.y, -N.z); /* two sided */
+    v3 Po = v3_make(fmaf(N.x, SHADOW_BIAS, P.x), fmaf(N.y, SHADOW_BIAS, P.y), fmaf(N.z, SHADOW_BIAS, P.z));
+    v3 rgb = v3_make(0.0f, 0.0f, 0.0f);
+    for (uint32_t li = 0; li < s->n_lights; li++) {
+        const oracle_light* L = &s->lights[li];
+        v3 Lv = v3_sub(v3_make(L->pos[0], L->pos[1], L->pos[2]), Po);
+        float r2 = v3_dot(Lv, Lv);
+        float dist = sqrtf(r2);
+        float invr = 1.0f / dist;
+        v3 Ld = v3_make(Lv.x * invr, Lv.y * invr, Lv.z * invr);
+        float cosv = fmaxf(0.0f, v3_dot(N, Ld));
+        if (cosv > 0.0f) {
+            ray sr;
+            ray_setup(&sr, Po, Ld);
+            (*n_shadow)++;
+            int occluded = brute ? brute_any(s, &sr, 0.0f, dist, c) : trace_any(s, &sr, 0.0f, dist, c);
+            if (!occluded) {
+                float k = (L->intensity / (FOUR_PI * r2)) * cosv;
+                rgb.x = fmaf(albedo.x, k, rgb.x);
+                rgb.y = fmaf(albedo.y, k, rgb.y);
+                rgb.z = fmaf(albedo.z, k, rgb.z);
+            }
+        }
+    }
+    return rgb;
+}
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+int oracle_render(const oracle_scene* s, const float pos[3], const float rot[9], uint32_t mode,
+                  const float miss_rgb[3], uint32_t w, uint32_t h,
+                  uint32_t y_begin, uint32_t y_end, uint32_t y_step,
+                  uint8_t* rgba8, uint32_t* hit_inst, uint32_t* hit_prim, float* hit_t, float* rgb_f32,
+                  oracle_stats* stats, int brute_force, int n_threads)
+{
+    if (!s || w == 0 || h == 0 || y_step == 0) return 1;
+    if (y_end > h) y_end = h;
+    const v3 o = v3_make(pos[0], pos[1], pos[2]);
+    const float width = (float)w, height = (float)h;
+    const v3 miss = miss_rgb ? v3_make(miss_rgb[0], miss_rgb[1], miss_rgb[2]) : v3_make(0.0f, 1.0f, 1.0f); /* hlsl:75 */
+    uint64_t tot_nodes = 0, tot_tris = 0, tot_shadow = 0, tot_primary = 0;
+    const long n_rows = y_begin < y_end ? (long)((y_end - y_begin + y_step - 1) / y_step) : 0;
+#ifdef _OPENMP
+    if (n_threads <= 0) n_threads = omp_get_max_threads();
+#else
+    n_threads = 1;
+#endif
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : tot_nodes, tot_tris, tot_shadow, tot_primary)
+    for (long row = 0; row < n_rows; row++) {
+        const uint32_t py = y_begin + (uint32_t)row * y_step;
+        trav_count c = { 0, 0 };
+        uint64_t n_shadow = 0;
+        for (uint32_t px = 0; px < w; px++) {
+            ray r;
+            hit_rec hr;
+            ray_setup(&r, o, ray_dir(rot, px, py, width, height));
+            if (brute_force) brute_closest(s, &r, RAY_TMIN, RAY_TMAX, &hr, &c);
+            else trace_closest(s, &r, RAY_TMIN, RAY_TMAX, &hr, &c);
+            v3 col = miss;
+            uint32_t inst = ORACLE_MISS, prim = ORACLE_MISS;
+            if (hr.hit) {
+                const oracle_tri* T = &s->tris[hr.tri];
+                inst = T->inst; prim = T->prim;
+                if (mode >= ORACLE_MODE_LAMBERT) col = shade_lambert(s, &r, &hr, brute_force, &c, &n_shadow);
+                else col = shade_debug(mode, inst, prim, hr.t, hr.u, hr.v, r.o, r.d);
+            }
+            const size_t pix = (size_t)py * w + px;
+            if (rgba8) {
+                rgba8[4 * pix + 0] = oracle_unorm8(col.x);
+                rgba8[4 * pix + 1] = oracle_unorm8(col.y);
+                rgba8[4 * pix + 2] = oracle_unorm8(col.z);
+                rgba8[4 * pix + 3] = 255; /* alpha = 1 (hlsl:55,75,168) */
+            }
+            if (hit_inst) hit_inst[pix] = inst;
+            if (hit_prim) hit_prim[pix] = prim;
+            if (hit_t) hit_t[pix] = hr.hit ? hr.t : RAY_TMAX;
+            if (rgb_f32) { rgb_f32[3 * pix] = col.x; rgb_f32[3 * pix + 1] = col.y; rgb_f32[3 * pix + 2] = col.z; }
+        }
+        tot_nodes += c.nodes; tot_tris += c.tris; tot_shadow += n_shadow; tot_primary += w;
+    }
+    if (stats) {
+        stats->rays_primary = tot_primary; stats->rays_shadow = tot_shadow;
+        stats->nodes_visited = tot_nodes; stats->tris_tested = tot_tris;
+        stats->pixels = tot_primary;
+    }
+    return 0;
+}
