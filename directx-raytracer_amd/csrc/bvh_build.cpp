@@ -1,0 +1,287 @@
+// Deterministic binned-SAH BVH2 builder (host).  See bvh_build.h and DESIGN.md "BVH build" for the spec;
+// tests/test_bvh.py checks the result against the oracle's independent restatement byte for byte.
+//
+// Structure: triangle bounds/centroids in SoA arrays; one recursive routine per index range that bins the
+// three axes in a single sweep; large ranges fork their left half as an OpenMP task (ranges are disjoint, so
+// the result does not depend on scheduling); nodes are allocated from a shared pool in arbitrary order and
+// renumbered to DFS pre-order at the end.
+#include "bvh_build.h"
+
+#include <atomic>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+namespace crt {
+namespace {
+
+inline float fmin_sel(float a, float b) { return a < b ? a : b; }
+inline float fmax_sel(float a, float b) { return a > b ? a : b; }
+
+struct Box {
+    float mn[3], mx[3];
+    void clear()
+    {
+        for (int a = 0; a < 3; a++) { mn[a] = std::numeric_limits<float>::infinity(); mx[a] = -std::numeric_limits<float>::infinity(); }
+    }
+    void grow(const Box& o)
+    {
+        for (int a = 0; a < 3; a++) { mn[a] = fmin_sel(mn[a], o.mn[a]); mx[a] = fmax_sel(mx[a], o.mx[a]); }
+    }
+    float halfArea() const
+    {
+        const float dx = mx[0] - mn[0], dy = mx[1] - mn[1], dz = mx[2] - mn[2];
+        return (dx * dy + dy * dz) + dz * dx;
+    }
+};
+
+struct TempNode {
+    Box lb, rb;
+    int32_t left, right; // >= 0: pool index, < 0: final leaf reference
+};
+
+inline int32_t leafRef(uint32_t first, uint32_t count) { return ~static_cast<int32_t>((first << 3) | count); }
+
+struct Builder {
+    const Box* primBox;
+    const float* cent; // 3 per triangle
+    uint32_t* order;
+    uint32_t* scratch;
+    TempNode* pool;
+    std::atomic<uint32_t> poolUsed{ 0 };
+    std::atomic<uint32_t> deepest{ 0 };
+
+    inline int binOf(uint32_t prim, int axis, float lo, float scale) const
+    {
+        int b = static_cast<int>((cent[3 * prim + axis] - lo) * scale);
+        return b > kBins - 1 ? kBins - 1 : b;
+    }
+
+    int32_t build(uint32_t first, uint32_t count, uint32_t depth, Box& bounds)
+    {
+        Box cb;
+        bounds.clear();
+        cb.clear();
+        for (uint32_t i = first; i < first + count; i++) {
+            const uint32_t p = order[i];
+            bounds.grow(primBox[p]);
+            for (int a = 0; a < 3; a++) {
+                const float c = cent[3 * p + a];
+                cb.mn[a] = fmin_sel(cb.mn[a], c);
+                cb.mx[a] = fmax_sel(cb.mx[a], c);
+            }
+        }
+        uint32_t seen = deepest.load(std::memory_order_relaxed);
+        while (depth > seen && !deepest.compare_exchange_weak(seen, depth, std::memory_order_relaxed)) {}
+        if (count <= 1 || depth >= static_cast<uint32_t>(kMaxDepth)) return leafRef(first, count);
+
+        // ---- bin all three axes in one sweep
+        Box binBox[3][kBins];
+        uint32_t binCnt[3][kBins];
+        float scale[3];
+        bool live[3];
+        for (int a = 0; a < 3; a++) {
+            const float ext = cb.mx[a] - cb.mn[a];
+            live[a] = ext > 0.0f;
+            scale[a] = live[a] ? static_cast<float>(kBins) / ext : 0.0f;
+            for (int b = 0; b < kBins; b++) { binBox[a][b].clear(); binCnt[a][b] = 0; }
+        }
+        for (uint32_t i = first; i < first + count; i++) {
+            const uint32_t p = order[i];
+            for (int a = 0; a < 3; a++) {
+                if (!live[a]) continue;
+                const int b = binOf(p, a, cb.mn[a], scale[a]);
+                binCnt[a][b]++;
+                binBox[a][b].grow(primBox[p]);
+            }
+        }
+        // ---- evaluate the 3 x 15 planes: axis ascending, plane ascending, first strict minimum wins
+        float bestCost = std::numeric_limits<float>::infinity();
+        int bestAxis = -1, bestPlane = 0;
+        for (int a = 0; a < 3; a++) {
+            if (!live[a]) continue;
+            Box suffix[kBins];
+            uint32_t suffixCnt[kBins];
+            Box acc;
+            acc.clear();
+            uint32_t n = 0;
+            for (int b = kBins - 1; b >= 1; b--) {
+                acc.grow(binBox[a][b]);
+                n += binCnt[a][b];
+                suffix[b] = acc;
+                suffixCnt[b] = n;
+            }
+            acc.clear();
+            n = 0;
+            for (int s = 1; s < kBins; s++) {
+                acc.grow(binBox[a][s - 1]);
+                n += binCnt[a][s - 1];
+                if (n == 0 || suffixCnt[s] == 0) continue;
+                const float cost = acc.halfArea() * static_cast<float>(n) + suffix[s].halfArea() * static_cast<float>(suffixCnt[s]);
+                if (cost < bestCost) { bestCost = cost; bestAxis = a; bestPlane = s; }
+            }
+        }
+
+        const float area = bounds.halfArea();
+        if (count <= static_cast<uint32_t>(kLeafMax)) {
+            if (bestAxis < 0 || !(kTravCost * area + bestCost < static_cast<float>(count) * area)) return leafRef(first, count);
+        }
+
+        uint32_t nLeft = 0;
+        if (bestAxis >= 0) {
+            uint32_t nl = 0, nr = 0;
+            const float lo = cb.mn[bestAxis], sc = scale[bestAxis];
+            for (uint32_t i = first; i < first + count; i++) { // stable partition
+                const uint32_t p = order[i];
+                if (binOf(p, bestAxis, lo, sc) < bestPlane) order[first + nl++] = p;
+                else scratch[first + nr++] = p;
+            }
+            std::memcpy(order + first + nl, scratch + first, sizeof(uint32_t) * nr);
+            nLeft = nl;
+            const uint64_t cap = static_cast<uint64_t>(kLeafMax) << (kMaxDepth - depth - 1);
+            if (static_cast<uint64_t>(nl > nr ? nl : nr) > cap) nLeft = 0;
+        }
+        if (nLeft == 0) nLeft = count / 2;
+
+        const uint32_t me = poolUsed.fetch_add(1, std::memory_order_relaxed);
+        TempNode& N = pool[me];
+        const uint32_t nRight = count - nLeft;
+        if (count >= 32768) {
+            int32_t l = 0;
+#pragma omp task shared(l, N) firstprivate(first, nLeft, depth)
+            l = build(first, nLeft, depth + 1, N.lb);
+            const int32_t r = build(first + nLeft, nRight, depth + 1, N.rb);
+#pragma omp taskwait
+            N.left = l;
+            N.right = r;
+        } else {
+            N.left = build(first, nLeft, depth + 1, N.lb);
+            N.right = build(first + nLeft, nRight, depth + 1, N.rb);
+        }
+        return static_cast<int32_t>(me);
+    }
+};
+
+void writeNode(crt_bvh_node& d, const TempNode& s)
+{
+    d.lx0 = s.lb.mn[0]; d.lx1 = s.lb.mx[0]; d.ly0 = s.lb.mn[1]; d.ly1 = s.lb.mx[1]; d.lz0 = s.lb.mn[2]; d.lz1 = s.lb.mx[2];
+    d.rx0 = s.rb.mn[0]; d.rx1 = s.rb.mx[0]; d.ry0 = s.rb.mn[1]; d.ry1 = s.rb.mx[1]; d.rz0 = s.rb.mn[2]; d.rz1 = s.rb.mx[2];
+    d.pad0 = 0;
+    d.pad1 = 0;
+}
+
+} // namespace
+
+void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
+{
+    uint64_t total = 0;
+    for (uint32_t m = 0; m < n_meshes; m++) {
+        if (meshes[m].n_triangles && (!meshes[m].xyz || !meshes[m].idx)) throw std::runtime_error("mesh with triangles but null vertex/index pointer");
+        total += meshes[m].n_triangles;
+    }
+    if (total >= (1ull << 28)) throw std::runtime_error("too many triangles (limit 2^28 - 1)");
+    const uint32_t n = static_cast<uint32_t>(total);
+
+    out.nodes.clear();
+    out.tris.clear();
+    out.shade.clear();
+    out.maxDepth = 0;
+    if (n == 0) return;
+
+    // ---- flatten: per-triangle records in input order, bounds, centroids
+    std::vector<crt_bvh_tri> inTri(n);
+    std::vector<crt_bvh_shade> inShade(n);
+    std::vector<Box> primBox(n);
+    std::vector<float> cent(3 * static_cast<size_t>(n));
+    uint32_t g = 0;
+    for (uint32_t m = 0; m < n_meshes; m++) {
+        const crt_mesh_view& M = meshes[m];
+        for (uint32_t t = 0; t < M.n_triangles; t++, g++) {
+            const uint32_t i0 = M.idx[3 * t], i1 = M.idx[3 * t + 1], i2 = M.idx[3 * t + 2];
+            if (i0 >= M.n_vertices || i1 >= M.n_vertices || i2 >= M.n_vertices) throw std::runtime_error("triangle index out of range");
+            const float* A = M.xyz + 3 * static_cast<size_t>(i0);
+            const float* B = M.xyz + 3 * static_cast<size_t>(i1);
+            const float* C = M.xyz + 3 * static_cast<size_t>(i2);
+            crt_bvh_tri& T = inTri[g];
+            for (int k = 0; k < 3; k++) {
+                T.v0[k] = A[k];
+                T.e1[k] = B[k] - A[k];
+                T.e2[k] = C[k] - A[k];
+                primBox[g].mn[k] = fmin_sel(fmin_sel(A[k], B[k]), C[k]);
+                primBox[g].mx[k] = fmax_sel(fmax_sel(A[k], B[k]), C[k]);
+                cent[3 * static_cast<size_t>(g) + k] = (primBox[g].mn[k] + primBox[g].mx[k]) * 0.5f;
+            }
+            T.inst = m;
+            T.prim = t;
+            T.gid = g;
+            crt_bvh_shade& S = inShade[g];
+            std::memset(&S, 0, sizeof(S));
+            S.material = static_cast<uint32_t>(M.material_index);
+            if (M.normals) {
+                std::memcpy(S.n0, M.normals + 3 * static_cast<size_t>(i0), 12);
+                std::memcpy(S.n1, M.normals + 3 * static_cast<size_t>(i1), 12);
+                std::memcpy(S.n2, M.normals + 3 * static_cast<size_t>(i2), 12);
+            }
+        }
+    }
+
+    std::vector<uint32_t> order(n), scratch(n);
+    for (uint32_t i = 0; i < n; i++) order[i] = i;
+    std::vector<TempNode> pool(n); // a binary tree over n leaves has < n inner nodes
+
+    Builder B;
+    B.primBox = primBox.data();
+    B.cent = cent.data();
+    B.order = order.data();
+    B.scratch = scratch.data();
+    B.pool = pool.data();
+    Box rootBox;
+    int32_t root = 0;
+#pragma omp parallel
+#pragma omp single
+    root = B.build(0, n, 0, rootBox);
+    out.maxDepth = B.deepest.load();
+
+    if (root < 0) {
+        // the whole scene fits one leaf: node 0 must exist, so wrap it; the right child is an empty leaf
+        // with the same box (an empty box would be 'hit' by the slab test's inf arithmetic)
+        TempNode t;
+        t.lb = rootBox;
+        t.rb = rootBox;
+        out.nodes.resize(1);
+        writeNode(out.nodes[0], t);
+        out.nodes[0].left = root;
+        out.nodes[0].right = leafRef(0, 0);
+    } else {
+        // ---- renumber to DFS pre-order (left subtree first)
+        const uint32_t used = B.poolUsed.load();
+        out.nodes.resize(used);
+        std::vector<int32_t> newIndex(used, -1);
+        std::vector<int32_t> stack;
+        stack.push_back(root);
+        uint32_t next = 0;
+        while (!stack.empty()) {
+            const int32_t t = stack.back();
+            stack.pop_back();
+            newIndex[t] = static_cast<int32_t>(next++);
+            if (pool[t].right >= 0) stack.push_back(pool[t].right);
+            if (pool[t].left >= 0) stack.push_back(pool[t].left);
+        }
+        for (uint32_t t = 0; t < used; t++) {
+            crt_bvh_node& d = out.nodes[newIndex[t]];
+            writeNode(d, pool[t]);
+            d.left = pool[t].left >= 0 ? newIndex[pool[t].left] : pool[t].left;
+            d.right = pool[t].right >= 0 ? newIndex[pool[t].right] : pool[t].right;
+        }
+    }
+
+    out.tris.resize(n);
+    out.shade.resize(n);
+    for (uint32_t i = 0; i < n; i++) {
+        out.tris[i] = inTri[order[i]];
+        out.shade[i] = inShade[order[i]];
+    }
+}
+
+} // namespace crt

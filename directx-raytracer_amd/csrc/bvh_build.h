@@ -1,0 +1,28 @@
+// Host BVH builder of the product: stands in for BuildRaytracingAccelerationStructure
+// (R/DXRTRenderer.cpp:548-806; driver-built BLAS per mesh + TLAS with identity transforms => one flat
+// world-space hierarchy here).  Deterministic binned SAH, spec in DESIGN.md "BVH build".
+#pragma once
+
+#include "../../include/crt_hip.h"
+
+#include <cstdint>
+#include <vector>
+
+namespace crt {
+
+constexpr int kLeafMax = 4;       // triangles per leaf
+constexpr int kMaxDepth = 32;     // leaves at depth <= kMaxDepth => traversal stack <= kMaxDepth entries
+constexpr int kBins = 16;
+constexpr float kTravCost = 1.0f; // SAH cost of an inner-node visit, in triangle tests
+
+struct Bvh {
+    std::vector<crt_bvh_node> nodes;   // 64 B each, DFS pre-order, node 0 = root
+    std::vector<crt_bvh_tri> tris;     // 48 B each, leaf order
+    std::vector<crt_bvh_shade> shade;  // 48 B each, leaf order
+    uint32_t maxDepth = 0;
+};
+
+// meshes in InstanceID order; triangle gid = running ordinal over meshes. Throws std::runtime_error on bad input.
+void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out);
+
+} // namespace crt

@@ -1,0 +1,603 @@
+// C ABI of libcrt_hip.so (include/crt_hip.h): renderer context over the HIP runtime + scene-layer accessors.
+// Each entry point cites the reference member it replaces in the header.  No CPU fallback exists here: every
+// render path ends in launchRender() (render_kernels.hip).
+#include "../../include/crt_hip.h"
+
+#include "bvh_build.h"
+#include "render_kernels.h"
+#include "scene.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <chrono>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+using crt::RenderParams;
+
+struct crt_scene {
+    crt::Scene scene;
+    // uint32 copies of the int index vectors are not needed: std::vector<int> is reinterpreted like the
+    // reference does for its index buffers (R/DXRTRenderer.cpp:314-315)
+};
+
+struct crt_ctx {
+    int device = 0;
+    hipStream_t ownStream = nullptr;
+    hipStream_t stream = nullptr;
+    hipEvent_t evStart = nullptr, evStop = nullptr;
+    std::string error;
+
+    crt::Bvh bvh; // host copy of what sits in HBM
+    void* dNodes = nullptr;
+    void* dTris = nullptr;
+    void* dShade = nullptr;
+    void* dLights = nullptr;
+    void* dMats = nullptr;
+    uint32_t nLights = 0, nMats = 0;
+    bool haveScene = false;
+
+    float pos[3] = { 0.f, 0.f, 0.f };
+    float rot[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f };
+    float miss[3] = { 0.f, 1.f, 1.f }; // hlsl:75
+    uint32_t mode = 0;                 // R/DXRTRenderer.h:246 default shading mode
+    bool counting = false;
+    unsigned long long* dCounters = nullptr;
+
+    // scratch frame buffers for the host-output path, grown on demand
+    void* dFrame[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
+    size_t dFrameBytes[5] = { 0, 0, 0, 0, 0 };
+};
+
+namespace {
+
+thread_local std::string g_createError;
+
+int fail(crt_ctx* ctx, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->error = buf;
+    else g_createError = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                                   \
+    do {                                                                                                     \
+        hipError_t e_ = (expr);                                                                              \
+        if (e_ != hipSuccess) return fail((ctx), CRT_EHIP, "%s failed: %s", #expr, hipGetErrorString(e_));   \
+    } while (0)
+
+void freeScene(crt_ctx* c)
+{
+    void** ptrs[] = { &c->dNodes, &c->dTris, &c->dShade, &c->dLights, &c->dMats };
+    for (void** p : ptrs) {
+        if (*p) (void)hipFree(*p);
+        *p = nullptr;
+    }
+    c->haveScene = false;
+}
+
+int ensureFrame(crt_ctx* c, int slot, size_t bytes)
+{
+    if (c->dFrameBytes[slot] >= bytes) return CRT_OK;
+    if (c->dFrame[slot]) (void)hipFree(c->dFrame[slot]);
+    c->dFrame[slot] = nullptr;
+    c->dFrameBytes[slot] = 0;
+    HIP_TRY(c, hipMalloc(&c->dFrame[slot], bytes));
+    c->dFrameBytes[slot] = bytes;
+    return CRT_OK;
+}
+
+uint32_t tilesFor(uint32_t w, uint32_t h) { return ((w + crt::kTile - 1) / crt::kTile) * ((h + crt::kTile - 1) / crt::kTile); }
+
+void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_t nRanks, RenderParams& p)
+{
+    std::memset(&p, 0, sizeof(p));
+    p.nodes = c->dNodes;
+    p.tris = c->dTris;
+    p.shade = c->dShade;
+    p.lights = c->dLights;
+    p.mats = c->dMats;
+    p.n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
+    p.n_tris = static_cast<uint32_t>(c->bvh.tris.size());
+    p.n_lights = c->nLights;
+    p.n_mats = c->nMats;
+    std::memcpy(p.pos, c->pos, sizeof(p.pos));
+    std::memcpy(p.rot, c->rot, sizeof(p.rot));
+    std::memcpy(p.miss, c->miss, sizeof(p.miss));
+    p.mode = c->mode;
+    p.width = w;
+    p.height = h;
+    p.tiles_x = (w + crt::kTile - 1) / crt::kTile;
+    p.tiles_y = (h + crt::kTile - 1) / crt::kTile;
+    p.rank = rank;
+    p.n_ranks = nRanks;
+    const uint32_t nTiles = p.tiles_x * p.tiles_y;
+    p.n_local_tiles = rank < nTiles ? (nTiles - rank + nRanks - 1) / nRanks : 0;
+    p.counters = c->dCounters;
+}
+
+// enqueue one frame; when stats != nullptr, bracket with events, synchronise and fill the timers/counters
+int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
+{
+    const bool counting = c->counting;
+    if (counting) HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 3 * sizeof(unsigned long long), c->stream));
+    if (stats) HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
+    const int rc = crt::launchRender(p, counting, c->stream);
+    if (rc != 0) return fail(c, CRT_EHIP, "render kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+    if (stats) {
+        HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
+        HIP_TRY(c, hipEventSynchronize(c->evStop));
+        float ms = 0.f;
+        HIP_TRY(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));
+        std::memset(stats, 0, sizeof(*stats));
+        stats->kernel_ms = ms;
+        stats->rays_primary = 0;
+        // pixels rendered by this launch
+        uint64_t pix = 0;
+        const uint32_t nTiles = p.tiles_x * p.tiles_y;
+        for (uint32_t k = p.rank; k < nTiles; k += p.n_ranks) {
+            const uint32_t tx = k % p.tiles_x, ty = k / p.tiles_x;
+            const uint32_t w = std::min<uint32_t>(crt::kTile, p.width - tx * crt::kTile);
+            const uint32_t h = std::min<uint32_t>(crt::kTile, p.height - ty * crt::kTile);
+            pix += static_cast<uint64_t>(w) * h;
+        }
+        stats->rays_primary = pix;
+        if (counting) {
+            unsigned long long host[3] = { 0, 0, 0 };
+            HIP_TRY(c, hipMemcpy(host, c->dCounters, sizeof(host), hipMemcpyDeviceToHost));
+            stats->nodes_visited = host[0];
+            stats->tris_tested = host[1];
+            stats->rays_shadow = host[2];
+        }
+    }
+    return CRT_OK;
+}
+
+int checkRenderable(crt_ctx* c, uint32_t w, uint32_t h)
+{
+    if (!c) return CRT_EINVAL;
+    if (!c->haveScene) return fail(c, CRT_ESTATE, "no scene uploaded: call crt_upload_scene first");
+    if (w == 0 || h == 0 || w > 65536 || h > 65536) return fail(c, CRT_EINVAL, "bad frame size %ux%u", w, h);
+    return CRT_OK;
+}
+
+} // namespace
+
+extern "C" {
+
+uint32_t crt_abi_version(void) { return CRT_ABI_VERSION; }
+
+int crt_create(crt_ctx** out, int device_id)
+{
+    if (!out) return fail(nullptr, CRT_EINVAL, "crt_create: out is NULL");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, CRT_ENODEVICE, "no HIP device available (%s); this library has no CPU fallback",
+                    e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device_id < 0 || device_id >= n) return fail(nullptr, CRT_EINVAL, "device_id %d out of range [0,%d)", device_id, n);
+    crt_ctx* c = new (std::nothrow) crt_ctx();
+    if (!c) return fail(nullptr, CRT_ENOMEM, "out of host memory");
+    c->device = device_id;
+    if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
+        (e = hipMalloc(reinterpret_cast<void**>(&c->dCounters), 3 * sizeof(unsigned long long))) != hipSuccess) {
+        const int rc = fail(nullptr, CRT_ENODEVICE, "HIP initialisation failed on device %d: %s", device_id, hipGetErrorString(e));
+        crt_destroy(c);
+        return rc;
+    }
+    c->stream = c->ownStream;
+    *out = c;
+    return CRT_OK;
+}
+
+void crt_destroy(crt_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    freeScene(c);
+    for (int i = 0; i < 5; i++)
+        if (c->dFrame[i]) (void)hipFree(c->dFrame[i]);
+    if (c->dCounters) (void)hipFree(c->dCounters);
+    if (c->evStart) (void)hipEventDestroy(c->evStart);
+    if (c->evStop) (void)hipEventDestroy(c->evStop);
+    if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    delete c;
+}
+
+const char* crt_last_error(const crt_ctx* c) { return c ? c->error.c_str() : g_createError.c_str(); }
+
+int crt_bvh_build_host(const crt_mesh_view* meshes, uint32_t n_meshes, crt_bvh_node** nodes, uint32_t* n_nodes,
+                       crt_bvh_tri** tris, crt_bvh_shade** shade, uint32_t* n_tris, uint32_t* max_depth)
+{
+    if ((!meshes && n_meshes) || !nodes || !n_nodes || !tris || !n_tris) return fail(nullptr, CRT_EINVAL, "crt_bvh_build_host: NULL argument");
+    try {
+        crt::Bvh b;
+        crt::buildBvh(meshes, n_meshes, b);
+        *n_nodes = static_cast<uint32_t>(b.nodes.size());
+        *n_tris = static_cast<uint32_t>(b.tris.size());
+        if (max_depth) *max_depth = b.maxDepth;
+        *nodes = static_cast<crt_bvh_node*>(std::malloc(sizeof(crt_bvh_node) * (b.nodes.size() + 1)));
+        *tris = static_cast<crt_bvh_tri*>(std::malloc(sizeof(crt_bvh_tri) * (b.tris.size() + 1)));
+        if (shade) *shade = static_cast<crt_bvh_shade*>(std::malloc(sizeof(crt_bvh_shade) * (b.tris.size() + 1)));
+        if (!*nodes || !*tris || (shade && !*shade)) return fail(nullptr, CRT_ENOMEM, "out of host memory");
+        std::memcpy(*nodes, b.nodes.data(), sizeof(crt_bvh_node) * b.nodes.size());
+        std::memcpy(*tris, b.tris.data(), sizeof(crt_bvh_tri) * b.tris.size());
+        if (shade) std::memcpy(*shade, b.shade.data(), sizeof(crt_bvh_shade) * b.shade.size());
+    } catch (const std::exception& ex) {
+        return fail(nullptr, CRT_EINVAL, "BVH build failed: %s", ex.what());
+    }
+    return CRT_OK;
+}
+
+void crt_free(void* p) { std::free(p); }
+
+int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes, const crt_light* lights, uint32_t n_lights,
+                     const crt_material* materials, uint32_t n_materials)
+{
+    if (!c) return CRT_EINVAL;
+    if ((!meshes && n_meshes) || (!lights && n_lights) || (!materials && n_materials)) return fail(c, CRT_EINVAL, "NULL array with non-zero count");
+    try {
+        crt::buildBvh(meshes, n_meshes, c->bvh);
+    } catch (const std::bad_alloc&) {
+        return fail(c, CRT_ENOMEM, "out of host memory while building the BVH");
+    } catch (const std::exception& ex) {
+        return fail(c, CRT_EINVAL, "BVH build failed: %s", ex.what());
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    freeScene(c);
+    const size_t nb = sizeof(crt_bvh_node) * c->bvh.nodes.size();
+    const size_t tb = sizeof(crt_bvh_tri) * c->bvh.tris.size();
+    const size_t sb = sizeof(crt_bvh_shade) * c->bvh.shade.size();
+    // +64 bytes of slack so that a speculative wide load of the last record stays inside the allocation
+    HIP_TRY(c, hipMalloc(&c->dNodes, nb + 64));
+    HIP_TRY(c, hipMalloc(&c->dTris, tb + 64));
+    HIP_TRY(c, hipMalloc(&c->dShade, sb + 64));
+    HIP_TRY(c, hipMalloc(&c->dLights, sizeof(crt_light) * (n_lights + 1)));
+    HIP_TRY(c, hipMalloc(&c->dMats, sizeof(crt_material) * (n_materials + 1)));
+    if (nb) HIP_TRY(c, hipMemcpy(c->dNodes, c->bvh.nodes.data(), nb, hipMemcpyHostToDevice));
+    if (tb) HIP_TRY(c, hipMemcpy(c->dTris, c->bvh.tris.data(), tb, hipMemcpyHostToDevice));
+    if (sb) HIP_TRY(c, hipMemcpy(c->dShade, c->bvh.shade.data(), sb, hipMemcpyHostToDevice));
+    if (n_lights) HIP_TRY(c, hipMemcpy(c->dLights, lights, sizeof(crt_light) * n_lights, hipMemcpyHostToDevice));
+    if (n_materials) HIP_TRY(c, hipMemcpy(c->dMats, materials, sizeof(crt_material) * n_materials, hipMemcpyHostToDevice));
+    c->nLights = n_lights;
+    c->nMats = n_materials;
+    c->haveScene = true;
+    return CRT_OK;
+}
+
+int crt_set_camera(crt_ctx* c, const float pos[3], const float rot[9])
+{
+    if (!c) return CRT_EINVAL;
+    if (!pos || !rot) return fail(c, CRT_EINVAL, "crt_set_camera: NULL argument");
+    std::memcpy(c->pos, pos, sizeof(c->pos));
+    std::memcpy(c->rot, rot, sizeof(c->rot));
+    return CRT_OK;
+}
+
+int crt_set_shading_mode(crt_ctx* c, uint32_t mode)
+{
+    if (!c) return CRT_EINVAL;
+    c->mode = mode;
+    return CRT_OK;
+}
+
+int crt_set_miss_color(crt_ctx* c, const float rgb[3])
+{
+    if (!c) return CRT_EINVAL;
+    if (!rgb) return fail(c, CRT_EINVAL, "crt_set_miss_color: NULL argument");
+    std::memcpy(c->miss, rgb, sizeof(c->miss));
+    return CRT_OK;
+}
+
+int crt_set_counting(crt_ctx* c, int enabled)
+{
+    if (!c) return CRT_EINVAL;
+    c->counting = enabled != 0;
+    return CRT_OK;
+}
+
+int crt_set_stream(crt_ctx* c, void* hip_stream)
+{
+    if (!c) return CRT_EINVAL;
+    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->ownStream;
+    return CRT_OK;
+}
+
+int crt_synchronize(crt_ctx* c)
+{
+    if (!c) return CRT_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    return CRT_OK;
+}
+
+int crt_render_frame_device(crt_ctx* c, uint32_t w, uint32_t h, void* d_rgba8, void* d_hit_inst, void* d_hit_prim,
+                            void* d_hit_t, void* d_rgb_f32, crt_frame_stats* stats)
+{
+    int rc = checkRenderable(c, w, h);
+    if (rc) return rc;
+    if (!d_rgba8) return fail(c, CRT_EINVAL, "d_rgba8 is NULL");
+    const auto t0 = std::chrono::steady_clock::now();
+    RenderParams p;
+    fillParams(c, w, h, 0, 1, p);
+    p.rgba8 = static_cast<uint32_t*>(d_rgba8);
+    p.hit_inst = static_cast<uint32_t*>(d_hit_inst);
+    p.hit_prim = static_cast<uint32_t*>(d_hit_prim);
+    p.hit_t = static_cast<float*>(d_hit_t);
+    p.rgb_f32 = static_cast<float*>(d_rgb_f32);
+    rc = runRender(c, p, stats);
+    if (rc) return rc;
+    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return CRT_OK;
+}
+
+int crt_render_frame(crt_ctx* c, uint32_t w, uint32_t h, uint8_t* rgba8, uint32_t* hit_inst, uint32_t* hit_prim, float* hit_t,
+                     float* rgb_f32, crt_frame_stats* stats)
+{
+    int rc = checkRenderable(c, w, h);
+    if (rc) return rc;
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(c, hipSetDevice(c->device));
+    const size_t n = static_cast<size_t>(w) * h;
+    void* host[5] = { rgba8, hit_inst, hit_prim, hit_t, rgb_f32 };
+    const size_t bytes[5] = { n * 4, n * 4, n * 4, n * 4, n * 12 };
+    for (int i = 0; i < 5; i++)
+        if (host[i] || i == 0)
+            if ((rc = ensureFrame(c, i, bytes[i])) != CRT_OK) return rc;
+    RenderParams p;
+    fillParams(c, w, h, 0, 1, p);
+    p.rgba8 = static_cast<uint32_t*>(c->dFrame[0]);
+    p.hit_inst = host[1] ? static_cast<uint32_t*>(c->dFrame[1]) : nullptr;
+    p.hit_prim = host[2] ? static_cast<uint32_t*>(c->dFrame[2]) : nullptr;
+    p.hit_t = host[3] ? static_cast<float*>(c->dFrame[3]) : nullptr;
+    p.rgb_f32 = host[4] ? static_cast<float*>(c->dFrame[4]) : nullptr;
+    crt_frame_stats local;
+    rc = runRender(c, p, stats ? stats : &local); // synchronous like the reference's renderFrame
+    if (rc) return rc;
+    for (int i = 0; i < 5; i++)
+        if (host[i]) HIP_TRY(c, hipMemcpyAsync(host[i], c->dFrame[i], bytes[i], hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return CRT_OK;
+}
+
+uint32_t crt_tile_count(uint32_t w, uint32_t h) { return tilesFor(w, h); }
+
+uint32_t crt_tile_slots(uint32_t w, uint32_t h, uint32_t n_ranks)
+{
+    if (n_ranks == 0) return 0;
+    return (tilesFor(w, h) + n_ranks - 1) / n_ranks;
+}
+
+int crt_render_tiles_device(crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_t n_ranks, void* d_staging, crt_frame_stats* stats)
+{
+    int rc = checkRenderable(c, w, h);
+    if (rc) return rc;
+    if (!d_staging || n_ranks == 0 || rank >= n_ranks) return fail(c, CRT_EINVAL, "bad tile arguments (rank %u of %u)", rank, n_ranks);
+    const auto t0 = std::chrono::steady_clock::now();
+    RenderParams p;
+    fillParams(c, w, h, rank, n_ranks, p);
+    p.staging = 1;
+    p.rgba8 = static_cast<uint32_t*>(d_staging);
+    rc = runRender(c, p, stats);
+    if (rc) return rc;
+    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return CRT_OK;
+}
+
+int crt_untile_device(crt_ctx* c, uint32_t w, uint32_t h, uint32_t n_ranks, const void* d_gathered, void* d_rgba8)
+{
+    if (!c) return CRT_EINVAL;
+    if (!d_gathered || !d_rgba8 || n_ranks == 0 || w == 0 || h == 0) return fail(c, CRT_EINVAL, "crt_untile_device: bad argument");
+    const int rc = crt::launchUntile(static_cast<const uint32_t*>(d_gathered), static_cast<uint32_t*>(d_rgba8), w, h, n_ranks,
+                                     crt_tile_slots(w, h, n_ranks), c->stream);
+    if (rc != 0) return fail(c, CRT_EHIP, "untile kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+    return CRT_OK;
+}
+
+int crt_bvh_info(const crt_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* max_depth)
+{
+    if (!c || !c->haveScene) return CRT_ESTATE;
+    if (n_nodes) *n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
+    if (n_tris) *n_tris = static_cast<uint32_t>(c->bvh.tris.size());
+    if (max_depth) *max_depth = c->bvh.maxDepth;
+    return CRT_OK;
+}
+
+int crt_bvh_export(const crt_ctx* c, crt_bvh_node* nodes, crt_bvh_tri* tris, crt_bvh_shade* shade)
+{
+    if (!c || !c->haveScene) return CRT_ESTATE;
+    if (nodes) std::memcpy(nodes, c->bvh.nodes.data(), sizeof(crt_bvh_node) * c->bvh.nodes.size());
+    if (tris) std::memcpy(tris, c->bvh.tris.data(), sizeof(crt_bvh_tri) * c->bvh.tris.size());
+    if (shade) std::memcpy(shade, c->bvh.shade.data(), sizeof(crt_bvh_shade) * c->bvh.shade.size());
+    return CRT_OK;
+}
+
+// ------------------------------------------------------------------------------------------- scene layer
+int crt_scene_load(const char* path, crt_scene** out, char* err, size_t err_len)
+{
+    if (!path || !out) return CRT_EINVAL;
+    *out = nullptr;
+    crt_scene* s = new (std::nothrow) crt_scene();
+    if (!s) return CRT_ENOMEM;
+    try {
+        s->scene.parseSceneFile(path);
+    } catch (const std::exception& ex) {
+        if (err && err_len) snprintf(err, err_len, "%s", ex.what());
+        delete s;
+        return std::strstr(ex.what(), "cannot open") ? CRT_EIO : CRT_EPARSE;
+    }
+    *out = s;
+    return CRT_OK;
+}
+
+int crt_scene_new(crt_scene** out)
+{
+    if (!out) return CRT_EINVAL;
+    *out = new (std::nothrow) crt_scene();
+    return *out ? CRT_OK : CRT_ENOMEM;
+}
+
+void crt_scene_free(crt_scene* s) { delete s; }
+
+int crt_scene_add_mesh(crt_scene* s, const float* xyz, uint32_t nv, const uint32_t* idx, uint32_t nt, int32_t material_index)
+{
+    if (!s || (!xyz && nv) || (!idx && nt)) return CRT_EINVAL;
+    for (uint32_t i = 0; i < 3 * nt; i++)
+        if (idx[i] >= nv) return CRT_EINVAL;
+    crt::Mesh& m = s->scene.addObject();
+    m.reserve(nv, 3 * static_cast<size_t>(nt));
+    for (uint32_t i = 0; i < nv; i++) m.addVertex(crt::Vector(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]));
+    for (uint32_t i = 0; i < 3 * nt; i++) m.addIndex(static_cast<int>(idx[i]));
+    m.setMaterialIndex(material_index);
+    m.calculateVertexNormals();
+    return CRT_OK;
+}
+
+int crt_scene_add_light(crt_scene* s, const float pos[3], float intensity)
+{
+    if (!s || !pos) return CRT_EINVAL;
+    s->scene.addLight(crt::Light(crt::Vector(pos[0], pos[1], pos[2]), intensity));
+    return CRT_OK;
+}
+
+int crt_scene_add_material(crt_scene* s, const crt_material* m)
+{
+    if (!s || !m) return CRT_EINVAL;
+    crt::Material mat;
+    mat.setType(static_cast<crt::MaterialType>(m->type <= 4 ? m->type : 0));
+    mat.setAlbedo(crt::Vector(m->albedo[0], m->albedo[1], m->albedo[2]));
+    mat.setSmoothShading(m->smooth != 0);
+    mat.setIor(m->ior);
+    s->scene.addMaterial(mat);
+    return CRT_OK;
+}
+
+uint32_t crt_scene_mesh_count(const crt_scene* s) { return s ? static_cast<uint32_t>(s->scene.getObjects().size()) : 0; }
+
+int crt_scene_mesh(const crt_scene* s, uint32_t i, crt_mesh_view* out)
+{
+    if (!s || !out || i >= s->scene.getObjects().size()) return CRT_EINVAL;
+    const crt::Mesh& m = s->scene.getObjects()[i];
+    out->xyz = m.getVertices().empty() ? nullptr : m.getVertices().data()->data();
+    out->idx = reinterpret_cast<const uint32_t*>(m.getIndices().data());
+    out->normals = m.getVertexNormals().size() == m.getVertices().size() && !m.getVertexNormals().empty()
+                       ? m.getVertexNormals().data()->data() : nullptr;
+    out->n_vertices = static_cast<uint32_t>(m.getVertices().size());
+    out->n_triangles = static_cast<uint32_t>(m.getIndices().size() / 3);
+    out->material_index = m.getMaterialIndex();
+    return CRT_OK;
+}
+
+uint32_t crt_scene_light_count(const crt_scene* s) { return s ? static_cast<uint32_t>(s->scene.getLights().size()) : 0; }
+
+int crt_scene_light(const crt_scene* s, uint32_t i, crt_light* out)
+{
+    if (!s || !out || i >= s->scene.getLights().size()) return CRT_EINVAL;
+    const crt::Light& l = s->scene.getLights()[i];
+    std::memcpy(out->pos, l.getPosition().data(), 12);
+    out->intensity = l.getIntensity();
+    return CRT_OK;
+}
+
+uint32_t crt_scene_material_count(const crt_scene* s) { return s ? static_cast<uint32_t>(s->scene.getMaterials().size()) : 0; }
+
+int crt_scene_material(const crt_scene* s, uint32_t i, crt_material* out)
+{
+    if (!s || !out || i >= s->scene.getMaterials().size()) return CRT_EINVAL;
+    const crt::Material& m = s->scene.getMaterials()[i];
+    std::memcpy(out->albedo, m.getAlbedo().data(), 12);
+    out->type = static_cast<uint32_t>(m.getType());
+    out->smooth = m.isSmoothShading() ? 1u : 0u;
+    out->ior = m.getIor();
+    return CRT_OK;
+}
+
+uint32_t crt_scene_texture_count(const crt_scene* s) { return s ? static_cast<uint32_t>(s->scene.getTextures().size()) : 0; }
+
+int crt_scene_settings(const crt_scene* s, uint32_t* width, uint32_t* height, float background_rgb[3])
+{
+    if (!s) return CRT_EINVAL;
+    const crt::Settings& st = s->scene.getSettings();
+    if (width) *width = static_cast<uint32_t>(st.imageWidth);
+    if (height) *height = static_cast<uint32_t>(st.imageHeight);
+    if (background_rgb) std::memcpy(background_rgb, st.backgroundColor.data(), 12);
+    return CRT_OK;
+}
+
+int crt_scene_camera_get(const crt_scene* s, float pos[3], float rot[9])
+{
+    if (!s) return CRT_EINVAL;
+    if (pos) std::memcpy(pos, s->scene.getCamera().getPosition().data(), 12);
+    if (rot) std::memcpy(rot, s->scene.getCamera().getRotationMatrix().data(), 36);
+    return CRT_OK;
+}
+
+int crt_scene_camera_set(crt_scene* s, const float pos[3], const float rot[9])
+{
+    if (!s) return CRT_EINVAL;
+    if (pos) s->scene.getCamera().setPosition(crt::Vector(pos[0], pos[1], pos[2]));
+    if (rot) s->scene.getCamera().setRotationMatrix(crt::Matrix(rot[0], rot[1], rot[2], rot[3], rot[4], rot[5], rot[6], rot[7], rot[8]));
+    return CRT_OK;
+}
+
+#define CAMERA_OP(name, call)                        \
+    int name                                         \
+    {                                                \
+        if (!s) return CRT_EINVAL;                   \
+        s->scene.getCamera().call;                   \
+        return CRT_OK;                               \
+    }
+CAMERA_OP(crt_scene_camera_rotate(crt_scene* s, float dyaw, float dpitch), rotate(dyaw, dpitch))
+CAMERA_OP(crt_scene_camera_zoom(crt_scene* s, float amount), zoom(amount))
+CAMERA_OP(crt_scene_camera_move_forward(crt_scene* s, float d), moveForward(d))
+CAMERA_OP(crt_scene_camera_move_right(crt_scene* s, float d), moveRight(d))
+CAMERA_OP(crt_scene_camera_pan(crt_scene* s, float deg), pan(deg))
+CAMERA_OP(crt_scene_camera_tilt(crt_scene* s, float deg), tilt(deg))
+CAMERA_OP(crt_scene_camera_roll(crt_scene* s, float deg), roll(deg))
+#undef CAMERA_OP
+
+int crt_scene_camera_pan_around_target(crt_scene* s, float degrees, const float target[3])
+{
+    if (!s || !target) return CRT_EINVAL;
+    s->scene.getCamera().panAroundTarget(degrees, crt::Vector(target[0], target[1], target[2]));
+    return CRT_OK;
+}
+
+int crt_upload_scene_from(crt_ctx* c, const crt_scene* s)
+{
+    if (!c) return CRT_EINVAL;
+    if (!s) return fail(c, CRT_EINVAL, "scene is NULL");
+    const uint32_t nm = crt_scene_mesh_count(s), nl = crt_scene_light_count(s), nmat = crt_scene_material_count(s);
+    std::vector<crt_mesh_view> meshes(nm);
+    std::vector<crt_light> lights(nl);
+    std::vector<crt_material> mats(nmat);
+    for (uint32_t i = 0; i < nm; i++) crt_scene_mesh(s, i, &meshes[i]);
+    for (uint32_t i = 0; i < nl; i++) crt_scene_light(s, i, &lights[i]);
+    for (uint32_t i = 0; i < nmat; i++) crt_scene_material(s, i, &mats[i]);
+    const int rc = crt_upload_scene(c, meshes.data(), nm, lights.data(), nl, mats.data(), nmat);
+    if (rc) return rc;
+    return crt_set_camera_from(c, s);
+}
+
+int crt_set_camera_from(crt_ctx* c, const crt_scene* s)
+{
+    if (!c) return CRT_EINVAL;
+    if (!s) return fail(c, CRT_EINVAL, "scene is NULL");
+    return crt_set_camera(c, s->scene.getCamera().getPosition().data(), s->scene.getCamera().getRotationMatrix().data());
+}
+
+} // extern "C"

@@ -1,0 +1,47 @@
+// Launch interface between the C-ABI layer (crt_api.cpp, host C++) and the HIP kernels (render_kernels.hip).
+#pragma once
+
+#include <cstdint>
+
+struct ihipStream_t;
+
+namespace crt {
+
+constexpr int kTile = 16;          // macro tile edge: one 256-thread workgroup = 4 wavefronts of 8x8 pixels
+constexpr int kStackEntries = 32;  // per-lane LDS traversal stack = kMaxDepth of the builder
+
+struct RenderParams {
+    // scene (HBM)
+    const void* nodes;   // crt_bvh_node[n_nodes], 64 B, 64-B aligned
+    const void* tris;    // crt_bvh_tri[n_tris], 48 B
+    const void* shade;   // crt_bvh_shade[n_tris], 48 B
+    const void* lights;  // crt_light[n_lights]
+    const void* mats;    // crt_material[n_mats]
+    uint32_t n_nodes, n_tris, n_lights, n_mats;
+    // per-frame constants: CameraCB (R/DXRTRenderer.h:54-59) + DebugCB (:68-72)
+    float pos[3];
+    float rot[9];
+    float miss[3];
+    uint32_t mode;
+    uint32_t width, height;
+    // tiling
+    uint32_t tiles_x, tiles_y;   // ceil(width/16), ceil(height/16)
+    uint32_t rank, n_ranks;      // this launch renders macro tiles k with k % n_ranks == rank
+    uint32_t n_local_tiles;      // grid size: number of such tiles
+    uint32_t staging;            // 0: write row-major frame buffers; 1: rgba8 goes to the tile-major staging buffer
+    // outputs (device pointers, nullable except rgba8)
+    uint32_t* rgba8;
+    uint32_t* hit_inst;
+    uint32_t* hit_prim;
+    float* hit_t;
+    float* rgb_f32;
+    unsigned long long* counters; // [0] nodes fetched, [1] triangles fetched, [2] shadow rays; used by the counting variant
+};
+
+// Enqueue the fused rayGen -> traverse -> shade -> store kernel. counting selects the instrumented variant.
+int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream);
+// tile-major gathered buffer -> row-major frame
+int launchUntile(const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height, uint32_t n_ranks,
+                 uint32_t slots, ihipStream_t* stream);
+
+} // namespace crt

@@ -1,0 +1,471 @@
+// HIP kernels for gfx950 (MI355X): the reference's per-pixel DXR program -- rayGen -> TraceRay -> miss /
+// closestHit -> image store (R/HLSL/ray_tracing_shaders.hlsl:21-169, dispatched by DispatchRays at
+// R/DXRTRenderer.cpp:1405) -- fused into one kernel, with the BVH traversal and the ray/triangle test the
+// reference leaves to the DXR driver written out.
+//
+// Mapping: one 256-thread workgroup = one 16x16-pixel macro tile = four wavefronts, each wavefront a coherent
+// 8x8-pixel ray packet.  Every lane owns one ray and a private traversal stack in LDS (entry e of thread t at
+// dword e*256+t: conflict free, no per-thread scratch memory, so the vector memory path only carries BVH data).
+// Nodes are 64-byte records (both child boxes in the parent) fetched as four dwordx4 loads, triangles 48-byte
+// records fetched as three.  Workgroups are dealt round-robin to the 8 XCDs; the tile index is remapped so
+// that each XCD works on a contiguous band of the frame and its private L2 keeps that band's subtrees.
+//
+// Arithmetic contract: identical, operation for operation, to oracle/crt_oracle.c (compiled with
+// -ffp-contract=off; fused multiply-adds only where fmaf()/fma() is written; correctly rounded / and sqrt).
+#include "render_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+namespace crt {
+namespace {
+
+constexpr float kTMin = 0.001f;   // hlsl:51
+constexpr float kTMax = 10000.0f; // hlsl:52
+constexpr float kDirEps = 1e-20f;
+constexpr float kCullPad = 1.00000381469726562f; // 1 + 2^-18, see oracle trace_closest
+constexpr float kShadowBias = 1e-3f;
+constexpr float kFourPi = 12.566370614359172f;
+constexpr int kDone = INT_MIN;    // traversal finished (not a valid leaf reference)
+constexpr int kBlock = 256;
+
+struct F3 { float x, y, z; };
+
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{ x, y, z }; }
+__device__ __forceinline__ F3 sub3(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b)
+{
+    return f3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+__device__ __forceinline__ F3 normalize3(F3 a)
+{
+    const float inv = 1.0f / sqrtf(dot3(a, a));
+    return f3(a.x * inv, a.y * inv, a.z * inv);
+}
+__device__ __forceinline__ float frac1(float x) { return x - floorf(x); }
+__device__ __forceinline__ float saturate1(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+__device__ __forceinline__ float lerp1(float a, float b, float t) { return a + t * (b - a); }
+
+// sin() with the operation sequence of oracle_sinf: Cody-Waite reduction by 2*pi in double, odd Taylor
+// polynomial to r^23 (Horner, fma), one rounding to float.  fp64 runs at full rate on CDNA4.
+__device__ __forceinline__ float sinContract(float x)
+{
+    const double xd = static_cast<double>(x);
+    const double k = rint(xd * 0x1.45f306dc9c883p-3);
+    double r = fma(-k, 0x1.921fb54442d18p+2, xd);
+    r = fma(-k, 0x1.1a62633145c07p-52, r);
+    const double r2 = r * r;
+    double p = -0x1.761b41316381ap-75;
+    p = fma(p, r2, 0x1.71b8ef6dcf572p-66);
+    p = fma(p, r2, -0x1.2f49b46814157p-57);
+    p = fma(p, r2, 0x1.952c77030ad4ap-49);
+    p = fma(p, r2, -0x1.ae7f3e733b81fp-41);
+    p = fma(p, r2, 0x1.6124613a86d09p-33);
+    p = fma(p, r2, -0x1.ae64567f544e4p-26);
+    p = fma(p, r2, 0x1.71de3a556c734p-19);
+    p = fma(p, r2, -0x1.a01a01a01a01ap-13);
+    p = fma(p, r2, 0x1.1111111111111p-7);
+    p = fma(p, r2, -0x1.5555555555555p-3);
+    p = p * r2;
+    return static_cast<float>(fma(p, r, r));
+}
+__device__ __forceinline__ float hashSin(float x, float k) { return frac1(sinContract(x) * k); }
+
+__device__ __forceinline__ uint32_t unorm8(float c) { return static_cast<uint32_t>(saturate1(c) * 255.0f + 0.5f); }
+
+struct Ray {
+    F3 o, d;
+    F3 idir, noid;
+};
+
+__device__ __forceinline__ float safeRcp(float d)
+{
+    const float ds = (fabsf(d) < kDirEps) ? copysignf(kDirEps, d) : d;
+    return 1.0f / ds;
+}
+
+__device__ __forceinline__ Ray makeRay(F3 o, F3 d)
+{
+    Ray r;
+    r.o = o;
+    r.d = d;
+    r.idir = f3(safeRcp(d.x), safeRcp(d.y), safeRcp(d.z));
+    r.noid = f3(-(o.x * r.idir.x), -(o.y * r.idir.y), -(o.z * r.idir.z));
+    return r;
+}
+
+// slab test of one child box; returns hit and the entry distance
+__device__ __forceinline__ bool boxTest(float x0, float x1, float y0, float y1, float z0, float z1, const Ray& r,
+                                        float tmin, float tmax, float& tnear)
+{
+    const float ax = fmaf(x0, r.idir.x, r.noid.x), bx = fmaf(x1, r.idir.x, r.noid.x);
+    const float ay = fmaf(y0, r.idir.y, r.noid.y), by = fmaf(y1, r.idir.y, r.noid.y);
+    const float az = fmaf(z0, r.idir.z, r.noid.z), bz = fmaf(z1, r.idir.z, r.noid.z);
+    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
+    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
+    tnear = tn;
+    return tn <= tf;
+}
+
+// Moeller-Trumbore, two sided; u = weight of v1, v = weight of v2.  NaN/inf from det == 0 fail the compares.
+__device__ __forceinline__ bool triTest(const Ray& r, const float4 a, const float4 b, const float4 c, float tmin,
+                                        float& t, float& u, float& v)
+{
+    const F3 e1 = f3(b.x, b.y, b.z), e2 = f3(c.x, c.y, c.z);
+    const F3 p = cross3(r.d, e2);
+    const float det = dot3(e1, p);
+    const float inv = 1.0f / det;
+    const F3 s = sub3(r.o, f3(a.x, a.y, a.z));
+    u = dot3(s, p) * inv;
+    const F3 q = cross3(s, e1);
+    v = dot3(r.d, q) * inv;
+    t = dot3(e2, q) * inv;
+    return (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin);
+}
+
+struct Hit {
+    float t, u, v;
+    uint32_t tri; // leaf-order triangle index
+    uint32_t gid;
+};
+
+template <bool COUNT>
+__device__ __forceinline__ void traceClosest(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                             uint32_t n_nodes, const Ray& r, float tmin, float tmax, int* stack,
+                                             Hit& h, uint32_t& cntNodes, uint32_t& cntTris)
+{
+    h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
+    int cur = n_nodes ? 0 : kDone;
+    int sp = 0;
+    float tcull = tmax * kCullPad; // boxes are culled against best_t * pad; changes only when a hit is accepted
+    while (cur != kDone) {
+        while (cur >= 0) {
+            const float4* N = nodes + 4 * static_cast<size_t>(cur);
+            const float4 n0 = N[0], n1 = N[1], n2 = N[2];
+            const int4 n3 = *reinterpret_cast<const int4*>(N + 3);
+            if (COUNT) cntNodes++;
+            float tnl, tnr;
+            const bool hl = boxTest(n0.x, n0.y, n0.z, n0.w, n2.x, n2.y, r, tmin, tcull, tnl);
+            const bool hr = boxTest(n1.x, n1.y, n1.z, n1.w, n2.z, n2.w, r, tmin, tcull, tnr);
+            if (hl & hr) {
+                const bool rightFirst = tnr < tnl;
+                stack[sp * kBlock] = rightFirst ? n3.x : n3.y;
+                sp++;
+                cur = rightFirst ? n3.y : n3.x;
+            } else if (hl) {
+                cur = n3.x;
+            } else if (hr) {
+                cur = n3.y;
+            } else if (sp == 0) {
+                cur = kDone;
+            } else {
+                sp--;
+                cur = stack[sp * kBlock];
+            }
+        }
+        if (cur != kDone) {
+            const uint32_t code = static_cast<uint32_t>(~cur);
+            const uint32_t first = code >> 3, cnt = code & 7u;
+            for (uint32_t i = first; i < first + cnt; i++) {
+                const float4* T = tris + 3 * static_cast<size_t>(i);
+                const float4 a = T[0], b = T[1], c = T[2];
+                if (COUNT) cntTris++;
+                float t, u, v;
+                if (triTest(r, a, b, c, tmin, t, u, v)) {
+                    const uint32_t gid = __float_as_uint(c.w);
+                    if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
+                        h.t = t; h.u = u; h.v = v; h.tri = i; h.gid = gid;
+                        tcull = t * kCullPad;
+                    }
+                }
+            }
+            if (sp == 0) {
+                cur = kDone;
+            } else {
+                sp--;
+                cur = stack[sp * kBlock];
+            }
+        }
+    }
+}
+
+template <bool COUNT>
+__device__ __forceinline__ bool traceAny(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                         uint32_t n_nodes, const Ray& r, float tmin, float tmax, int* stack,
+                                         uint32_t& cntNodes, uint32_t& cntTris)
+{
+    bool occluded = false;
+    int cur = n_nodes ? 0 : kDone;
+    int sp = 0;
+    const float tcull = tmax * kCullPad;
+    while (cur != kDone) {
+        while (cur >= 0) {
+            const float4* N = nodes + 4 * static_cast<size_t>(cur);
+            const float4 n0 = N[0], n1 = N[1], n2 = N[2];
+            const int4 n3 = *reinterpret_cast<const int4*>(N + 3);
+            if (COUNT) cntNodes++;
+            float tnl, tnr;
+            const bool hl = boxTest(n0.x, n0.y, n0.z, n0.w, n2.x, n2.y, r, tmin, tcull, tnl);
+            const bool hr = boxTest(n1.x, n1.y, n1.z, n1.w, n2.z, n2.w, r, tmin, tcull, tnr);
+            if (hl & hr) {
+                const bool rightFirst = tnr < tnl;
+                stack[sp * kBlock] = rightFirst ? n3.x : n3.y;
+                sp++;
+                cur = rightFirst ? n3.y : n3.x;
+            } else if (hl) {
+                cur = n3.x;
+            } else if (hr) {
+                cur = n3.y;
+            } else if (sp == 0) {
+                cur = kDone;
+            } else {
+                sp--;
+                cur = stack[sp * kBlock];
+            }
+        }
+        if (cur != kDone) {
+            const uint32_t code = static_cast<uint32_t>(~cur);
+            const uint32_t first = code >> 3, cnt = code & 7u;
+            for (uint32_t i = first; i < first + cnt; i++) {
+                const float4* T = tris + 3 * static_cast<size_t>(i);
+                const float4 a = T[0], b = T[1], c = T[2];
+                if (COUNT) cntTris++;
+                float t, u, v;
+                if (triTest(r, a, b, c, tmin, t, u, v) & (t < tmax)) {
+                    occluded = true;
+                    break;
+                }
+            }
+            if (occluded | (sp == 0)) {
+                cur = kDone;
+            } else {
+                sp--;
+                cur = stack[sp * kBlock];
+            }
+        }
+    }
+    return occluded;
+}
+
+// rayGen (hlsl:21-55) with width/height as parameters instead of the literals 1920/1080 (hlsl:24-25)
+__device__ __forceinline__ F3 rayDir(const float* rot, uint32_t px, uint32_t py, float width, float height)
+{
+    float x = static_cast<float>(px), y = static_cast<float>(py);
+    x += 0.5f;
+    y += 0.5f;
+    x /= width;
+    y /= height;
+    x = (2.0f * x) - 1.0f;
+    y = 1.0f - (2.0f * y);
+    x *= width / height;
+    const F3 dc = normalize3(f3(x, y, -1.0f));
+    const F3 dw = f3(dot3(f3(rot[0], rot[1], rot[2]), dc), dot3(f3(rot[3], rot[4], rot[5]), dc),
+                     dot3(f3(rot[6], rot[7], rot[8]), dc));
+    return normalize3(dw);
+}
+
+__device__ __forceinline__ F3 objectBaseColour(uint32_t inst) // hlsl:97-101,117-121
+{
+    const float f = static_cast<float>(inst);
+    return f3(hashSin(f * 12.9898f, 43758.5453f), hashSin(f * 78.233f, 12345.6789f), hashSin(f * 39.425f, 34567.8901f));
+}
+
+// closestHit, modes 0..6 (hlsl:78-169)
+__device__ __forceinline__ F3 shadeDebug(uint32_t mode, uint32_t inst, uint32_t prim, float t, float u, float v, F3 o, F3 d)
+{
+    const F3 wp = f3(o.x + d.x * t, o.y + d.y * t, o.z + d.z * t);
+    if (mode == 0) {
+        const float f = static_cast<float>(prim);
+        return f3(hashSin(f * 12.9898f, 43758.5453f), hashSin(f * 78.233f, 43758.5453f), hashSin(f * 45.164f, 43758.5453f));
+    }
+    if (mode == 1) {
+        const F3 base = objectBaseColour(inst);
+        const int cx = static_cast<int>(floorf(wp.x / 2.0f)), cy = static_cast<int>(floorf(wp.y / 2.0f)),
+                  cz = static_cast<int>(floorf(wp.z / 2.0f));
+        const uint32_t hash = (static_cast<uint32_t>(cx) * 73856093u) ^ (static_cast<uint32_t>(cy) * 19349663u) ^
+                              (static_cast<uint32_t>(cz) * 83492791u);
+        const float variation = hashSin(static_cast<float>(hash) * 12.9898f, 43758.5453f);
+        return f3(lerp1(base.x * 0.7f, base.x * 1.3f, variation), lerp1(base.y * 0.7f, base.y * 1.3f, variation),
+                  lerp1(base.z * 0.7f, base.z * 1.3f, variation));
+    }
+    if (mode == 2) {
+        const F3 base = objectBaseColour(inst);
+        const float shade = hashSin(static_cast<float>(prim) * 12.9898f, 43758.5453f);
+        const float k = lerp1(0.6f, 1.0f, shade);
+        return f3(base.x * k, base.y * k, base.z * k);
+    }
+    if (mode == 3) return f3(1.0f - u - v, u, v);
+    if (mode == 4) {
+        const float h = saturate1((wp.y + 10.0f) / 20.0f);
+        return f3(lerp1(0.1f, 0.9f, h), lerp1(0.2f, 0.9f, h), lerp1(0.6f, 0.9f, h));
+    }
+    if (mode == 5) {
+        const float c = saturate1(t * 0.05f);
+        return f3(c, c, c);
+    }
+    const int checker = (static_cast<int>(floorf(wp.x)) ^ static_cast<int>(floorf(wp.z))) & 1;
+    const float c = checker ? 0.9f : 0.2f;
+    return f3(c, c, c);
+}
+
+struct LightRec { float x, y, z, intensity; };
+struct MaterialRec { float r, g, b; uint32_t type; uint32_t smooth; float ior; };
+
+// Lambert + one shadow ray per light (mode 100): extension, specified by oracle/crt_oracle.c shade_lambert
+template <bool COUNT>
+__device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* nodes, const float4* tris, const Ray& r,
+                                           const Hit& h, int* stack, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
+{
+    const float4* T = tris + 3 * static_cast<size_t>(h.tri);
+    const float4 tb = T[1], tc = T[2];
+    const float* S = reinterpret_cast<const float*>(p.shade) + 12 * static_cast<size_t>(h.tri);
+    const uint32_t material = __float_as_uint(S[9]);
+    const F3 P = f3(r.o.x + r.d.x * h.t, r.o.y + r.d.y * h.t, r.o.z + r.d.z * h.t);
+    F3 albedo = f3(1.0f, 1.0f, 1.0f);
+    bool smooth = false;
+    if (material < p.n_mats) {
+        const MaterialRec* M = reinterpret_cast<const MaterialRec*>(p.mats) + material;
+        albedo = f3(M->r, M->g, M->b);
+        smooth = M->smooth != 0;
+    }
+    F3 N = cross3(f3(tb.x, tb.y, tb.z), f3(tc.x, tc.y, tc.z));
+    if (smooth) {
+        const float w = 1.0f - h.u - h.v;
+        const F3 Ns = f3(fmaf(S[6], h.v, fmaf(S[3], h.u, S[0] * w)), fmaf(S[7], h.v, fmaf(S[4], h.u, S[1] * w)),
+                         fmaf(S[8], h.v, fmaf(S[5], h.u, S[2] * w)));
+        if (dot3(Ns, Ns) > 0.0f) N = Ns;
+    }
+    N = normalize3(N);
+    if (dot3(N, r.d) > 0.0f) N = f3(-N.x, -N.y, -N.z);
+    const F3 Po = f3(fmaf(N.x, kShadowBias, P.x), fmaf(N.y, kShadowBias, P.y), fmaf(N.z, kShadowBias, P.z));
+    F3 rgb = f3(0.0f, 0.0f, 0.0f);
+    const LightRec* lights = reinterpret_cast<const LightRec*>(p.lights);
+    for (uint32_t li = 0; li < p.n_lights; li++) {
+        const LightRec L = lights[li];
+        const F3 Lv = sub3(f3(L.x, L.y, L.z), Po);
+        const float r2 = dot3(Lv, Lv);
+        const float dist = sqrtf(r2);
+        const float invr = 1.0f / dist;
+        const F3 Ld = f3(Lv.x * invr, Lv.y * invr, Lv.z * invr);
+        const float cosv = fmaxf(0.0f, dot3(N, Ld));
+        if (cosv > 0.0f) {
+            const Ray sr = makeRay(Po, Ld);
+            if (COUNT) cntShadow++;
+            const bool occluded = traceAny<COUNT>(nodes, tris, p.n_nodes, sr, 0.0f, dist, stack, cntNodes, cntTris);
+            if (!occluded) {
+                const float k = (L.intensity / (kFourPi * r2)) * cosv;
+                rgb.x = fmaf(albedo.x, k, rgb.x);
+                rgb.y = fmaf(albedo.y, k, rgb.y);
+                rgb.z = fmaf(albedo.z, k, rgb.z);
+            }
+        }
+    }
+    return rgb;
+}
+
+__device__ __forceinline__ uint32_t waveSum(uint32_t v)
+{
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+template <bool COUNT>
+__global__ __launch_bounds__(kBlock) void renderKernel(const RenderParams p)
+{
+    __shared__ int s_stack[kStackEntries * kBlock];
+
+    // XCD-aware remap: workgroup b runs on XCD b % 8 (observed round-robin); give XCD x the x-th contiguous
+    // chunk of this rank's tile list.  Bijective for any grid size; affects speed only.
+    const uint32_t nblk = gridDim.x, b = blockIdx.x;
+    const uint32_t q = nblk >> 3, rem = nblk & 7u, xcd = b & 7u;
+    const uint32_t j = xcd * q + (xcd < rem ? xcd : rem) + (b >> 3);
+    const uint32_t k = j * p.n_ranks + p.rank; // global macro-tile index, row-major
+    if (k >= p.tiles_x * p.tiles_y) return;
+    const uint32_t tile_x = k % p.tiles_x, tile_y = k / p.tiles_x;
+
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
+    const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
+    const bool active = (px < p.width) & (py < p.height);
+
+    uint32_t cntNodes = 0, cntTris = 0, cntShadow = 0;
+    if (active) {
+        const float4* nodes = reinterpret_cast<const float4*>(p.nodes);
+        const float4* tris = reinterpret_cast<const float4*>(p.tris);
+        int* stack = s_stack + tid;
+
+        const F3 o = f3(p.pos[0], p.pos[1], p.pos[2]);
+        const Ray r = makeRay(o, rayDir(p.rot, px, py, static_cast<float>(p.width), static_cast<float>(p.height)));
+        Hit h;
+        traceClosest<COUNT>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, h, cntNodes, cntTris);
+
+        F3 col = f3(p.miss[0], p.miss[1], p.miss[2]); // miss shader (hlsl:72-76)
+        uint32_t inst = 0xFFFFFFFFu, prim = 0xFFFFFFFFu;
+        const bool hit = h.t < kTMax;
+        if (hit) {
+            const float4* T = tris + 3 * static_cast<size_t>(h.tri);
+            inst = __float_as_uint(T[0].w);
+            prim = __float_as_uint(T[1].w);
+            if (p.mode >= 100u) col = shadeLambert<COUNT>(p, nodes, tris, r, h, stack, cntNodes, cntTris, cntShadow);
+            else col = shadeDebug(p.mode, inst, prim, h.t, h.u, h.v, r.o, r.d);
+        }
+
+        const uint32_t packed = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
+        const size_t pix = static_cast<size_t>(py) * p.width + px;
+        if (p.staging) p.rgba8[static_cast<size_t>(j) * (kTile * kTile) + ly * kTile + lx] = packed;
+        else p.rgba8[pix] = packed;
+        if (p.hit_inst) p.hit_inst[pix] = inst;
+        if (p.hit_prim) p.hit_prim[pix] = prim;
+        if (p.hit_t) p.hit_t[pix] = hit ? h.t : kTMax;
+        if (p.rgb_f32) {
+            p.rgb_f32[3 * pix + 0] = col.x;
+            p.rgb_f32[3 * pix + 1] = col.y;
+            p.rgb_f32[3 * pix + 2] = col.z;
+        }
+    }
+    if (COUNT) {
+        const uint32_t a = waveSum(cntNodes), c = waveSum(cntTris), s = waveSum(cntShadow);
+        if (lane == 0) {
+            atomicAdd(&p.counters[0], static_cast<unsigned long long>(a));
+            atomicAdd(&p.counters[1], static_cast<unsigned long long>(c));
+            atomicAdd(&p.counters[2], static_cast<unsigned long long>(s));
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void untileKernel(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame,
+                                                       uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_ranks,
+                                                       uint32_t slots)
+{
+    const uint32_t px = blockIdx.x * 64u + (threadIdx.x & 63u);
+    const uint32_t py = blockIdx.y * 4u + (threadIdx.x >> 6);
+    if (px >= width || py >= height) return;
+    const uint32_t k = (py / kTile) * tiles_x + px / kTile;
+    const uint32_t rank = k % n_ranks, slot = k / n_ranks;
+    const size_t src = (static_cast<size_t>(rank) * slots + slot) * (kTile * kTile) + (py % kTile) * kTile + (px % kTile);
+    frame[static_cast<size_t>(py) * width + px] = gathered[src];
+}
+
+} // namespace
+
+int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream)
+{
+    if (p.n_local_tiles == 0) return 0;
+    const dim3 grid(p.n_local_tiles), block(kBlock);
+    if (counting) hipLaunchKernelGGL(renderKernel<true>, grid, block, 0, stream, p);
+    else hipLaunchKernelGGL(renderKernel<false>, grid, block, 0, stream, p);
+    return static_cast<int>(hipGetLastError());
+}
+
+int launchUntile(const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height, uint32_t n_ranks,
+                 uint32_t slots, ihipStream_t* stream)
+{
+    const uint32_t tiles_x = (width + kTile - 1) / kTile;
+    const dim3 grid((width + 63) / 64, (height + 3) / 4), block(kBlock);
+    hipLaunchKernelGGL(untileKernel, grid, block, 0, stream, gathered, frame, width, height, tiles_x, n_ranks, slots);
+    return static_cast<int>(hipGetLastError());
+}
+
+} // namespace crt

@@ -37,6 +37,7 @@
 #define MAX_DEPTH 32      /* leaves at depth <= MAX_DEPTH  => traversal stack <= MAX_DEPTH entries */
 #define N_BINS 16
 #define C_TRAV 1.0f       /* SAH: cost of visiting an inner node, in triangle tests */
+#define CULL_PAD 1.00000381469726562f /* 1 + 2^-18: boxes are culled against best_t * CULL_PAD (see trace_closest) */
 #define SHADOW_BIAS 1e-3f
 #define FOUR_PI 12.566370614359172f
 
@@ -413,7 +414,10 @@ static inline int box_test(float x0, float x1, float y0, float y1, float z0, flo
     return tn <= tf;
 }
 
-/* closest hit in (tmin, tmax); equal t resolved towards the lower global triangle ordinal */
+/* closest hit in (tmin, tmax); equal t resolved towards the lower global triangle ordinal.
+ * Boxes are culled against tcull = best_t * CULL_PAD, not best_t: the slab distances and the Moeller-Trumbore t
+ * round differently, and without the pad a box holding an equal-t (or one-ulp-closer) triangle on a shared edge
+ * can be culled, making the winner depend on traversal order. tcull changes only when a hit is accepted. */
 static void trace_closest(const oracle_scene* s, const ray* r, float tmin, float tmax, hit_rec* h, trav_count* c)
 {
     h->t = tmax; h->u = 0.0f; h->v = 0.0f; h->tri = 0; h->gid = 0; h->hit = 0;
@@ -421,13 +425,14 @@ static void trace_closest(const oracle_scene* s, const ray* r, float tmin, float
     int32_t stack[MAX_DEPTH + 1];
     int sp = 0;
     int32_t cur = 0;
+    float tcull = tmax * CULL_PAD;
     for (;;) {
         if (cur >= 0) {
             const oracle_node* N = &s->nodes[cur];
             c->nodes++;
             float tnl, tnr;
-            int hl = box_test(N->lx0, N->lx1, N->ly0, N->ly1, N->lz0, N->lz1, r, tmin, h->t, &tnl);
-            int hr = box_test(N->rx0, N->rx1, N->ry0, N->ry1, N->rz0, N->rz1, r, tmin, h->t, &tnr);
+            int hl = box_test(N->lx0, N->lx1, N->ly0, N->ly1, N->lz0, N->lz1, r, tmin, tcull, &tnl);
+            int hr = box_test(N->rx0, N->rx1, N->ry0, N->ry1, N->rz0, N->rz1, r, tmin, tcull, &tnr);
             if (hl & hr) {
                 int right_first = tnr < tnl;
                 stack[sp++] = right_first ? N->left : N->right;
@@ -446,6 +451,7 @@ static void trace_closest(const oracle_scene* s, const ray* r, float tmin, float
                 if (tri_test(r, T, tmin, &t, &u, &v)) {
                     if ((t < h->t) | ((t == h->t) & (T->gid < h->gid))) {
                         h->t = t; h->u = u; h->v = v; h->tri = i; h->gid = T->gid; h->hit = 1;
+                        tcull = t * CULL_PAD;
                     }
                 }
             }
@@ -462,13 +468,14 @@ static int trace_any(const oracle_scene* s, const ray* r, float tmin, float tmax
     int32_t stack[MAX_DEPTH + 1];
     int sp = 0;
     int32_t cur = 0;
+    const float tcull = tmax * CULL_PAD;
     for (;;) {
         if (cur >= 0) {
             const oracle_node* N = &s->nodes[cur];
             c->nodes++;
             float tnl, tnr;
-            int hl = box_test(N->lx0, N->lx1, N->ly0, N->ly1, N->lz0, N->lz1, r, tmin, tmax, &tnl);
-            int hr = box_test(N->rx0, N->rx1, N->ry0, N->ry1, N->rz0, N->rz1, r, tmin, tmax, &tnr);
+            int hl = box_test(N->lx0, N->lx1, N->ly0, N->ly1, N->lz0, N->lz1, r, tmin, tcull, &tnl);
+            int hr = box_test(N->rx0, N->rx1, N->ry0, N->ry1, N->rz0, N->rz1, r, tmin, tcull, &tnr);
             if (hl & hr) {
                 int right_first = tnr < tnl;
                 stack[sp++] = right_first ? N->left : N->right;

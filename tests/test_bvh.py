@@ -1,0 +1,123 @@
+"""The product's host BVH builder (crt_bvh_build_host, csrc/bvh_build.cpp) against the oracle's independent
+restatement of the same spec (byte-identical trees) and against structural invariants."""
+import numpy as np
+import pytest
+
+
+def _check_structure(nodes, tris, n_input, max_depth_reported):
+    """every triangle in exactly one leaf, leaves <= 4 triangles, child boxes bound their triangles, depth <= 32,
+    nodes in DFS pre-order."""
+    if n_input == 0:
+        assert len(nodes) == 0 and len(tris) == 0
+        return
+    seen = np.zeros(len(tris), dtype=np.int32)
+    v0 = tris["v0"].astype(np.float64)
+    v1 = v0 + tris["e1"]
+    v2 = v0 + tris["e2"]
+    tmin = np.minimum(np.minimum(v0, v1), v2)
+    tmax = np.maximum(np.maximum(v0, v1), v2)
+    order = []
+    stack = [(0, 0)]
+    deepest = 0
+    while stack:
+        i, depth = stack.pop()
+        order.append(i)
+        n = nodes[i]
+        for side, ref in (("l", int(n["left"])), ("r", int(n["right"]))):
+            lo = np.array([n[side + "x0"], n[side + "y0"], n[side + "z0"]], dtype=np.float64)
+            hi = np.array([n[side + "x1"], n[side + "y1"], n[side + "z1"]], dtype=np.float64)
+            if ref >= 0:
+                assert ref > i, "children come after parents"
+                c = nodes[ref]
+                clo = np.minimum([c["lx0"], c["ly0"], c["lz0"]], [c["rx0"], c["ry0"], c["rz0"]])
+                chi = np.maximum([c["lx1"], c["ly1"], c["lz1"]], [c["rx1"], c["ry1"], c["rz1"]])
+                assert np.all(clo >= lo - 1e-6) and np.all(chi <= hi + 1e-6)
+            else:
+                code = ~ref & 0xFFFFFFFF
+                first, cnt = code >> 3, code & 7
+                assert cnt <= 4 and first + cnt <= len(tris)
+                deepest = max(deepest, depth + 1)
+                if cnt:
+                    seen[first:first + cnt] += 1
+                    assert np.all(tmin[first:first + cnt] >= lo - 1e-5) and np.all(tmax[first:first + cnt] <= hi + 1e-5)
+                    # leaf boxes are tight unions (vertices are rebuilt from v0 + edge here, hence the ulp of slack)
+                    np.testing.assert_allclose(tmin[first:first + cnt].min(axis=0), lo, rtol=1e-6, atol=1e-6)
+                    np.testing.assert_allclose(tmax[first:first + cnt].max(axis=0), hi, rtol=1e-6, atol=1e-6)
+        if int(n["right"]) >= 0:
+            stack.append((int(n["right"]), depth + 1))
+        if int(n["left"]) >= 0:
+            stack.append((int(n["left"]), depth + 1))
+    assert np.all(seen == 1), "every triangle in exactly one leaf"
+    assert order == list(range(len(nodes))), "DFS pre-order"
+    assert deepest <= 32 and max_depth_reported <= 32
+    assert sorted(tris["gid"].tolist()) == list(range(n_input))
+
+
+def _compare(pkg, oracle, meshes):
+    nodes, tris, shade, md = pkg.build_bvh_host(meshes)
+    O = oracle.OracleScene(meshes)
+    assert nodes.tobytes() == O.nodes().tobytes()
+    assert tris.tobytes() == O.tris().tobytes()
+    assert shade.tobytes() == O.shade().tobytes()
+    assert md == O.max_depth
+    _check_structure(nodes, tris, sum(len(m["triangles"]) for m in meshes), md)
+    return nodes, tris
+
+
+@pytest.mark.parametrize("name", ["cornell", "dragon", "sphere", "single", "soup"])
+def test_product_builder_equals_oracle_builder(pkg, oracle, scenes, dragon, name):
+    sc = {"cornell": scenes.cornell_box, "dragon": lambda: dragon, "sphere": lambda: scenes.displaced_sphere(60, 60),
+          "single": scenes.single_triangle, "soup": lambda: scenes.icosphere_soup(40, 2)}[name]()
+    nodes, tris = _compare(pkg, oracle, sc["meshes"])
+    if name == "dragon":
+        assert len(tris) == 4014
+
+
+def test_large_scene_parallel_build_is_deterministic(pkg, oracle, scenes):
+    """> 32768 triangles takes the OpenMP task path; result must equal the serial oracle build and itself."""
+    sc = scenes.heightfield(n=160)
+    a = pkg.build_bvh_host(sc["meshes"])
+    b = pkg.build_bvh_host(sc["meshes"])
+    assert a[0].tobytes() == b[0].tobytes() and a[1].tobytes() == b[1].tobytes()
+    _compare(pkg, oracle, sc["meshes"])
+
+
+def test_edge_cases(pkg, oracle):
+    f = np.float32
+    tri = f([(0, 0, 0), (1, 0, 0), (0, 1, 0)])
+    # empty scene, empty mesh
+    nodes, tris, shade, md = pkg.build_bvh_host([])
+    assert len(nodes) == 0 and len(tris) == 0
+    _compare(pkg, oracle, [{"vertices": np.zeros((0, 3), f), "triangles": np.zeros((0, 3), np.uint32)}])
+    # scenes of 1..5 triangles (root-is-a-leaf wrapping up to 4)
+    for n in range(1, 6):
+        v = np.concatenate([tri + f([2 * i, 0, 0]) for i in range(n)])
+        t = np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)
+        nodes, _ = _compare(pkg, oracle, [{"vertices": v, "triangles": t}])
+        assert len(nodes) >= 1
+    # 37 identical triangles: all centroids equal -> no SAH plane exists -> median splits down to leaves of <= 4
+    v = np.concatenate([tri] * 37)
+    t = np.arange(3 * 37, dtype=np.uint32).reshape(-1, 3)
+    _compare(pkg, oracle, [{"vertices": v, "triangles": t}])
+    # degenerate (zero-area) and axis-aligned flat triangles
+    v = f([(0, 0, 0), (0, 0, 0), (0, 0, 0), (1, 1, 1), (2, 1, 1), (1, 2, 1), (5, 5, 5), (5, 5, 5), (6, 5, 5)])
+    _compare(pkg, oracle, [{"vertices": v, "triangles": np.uint32([(0, 1, 2), (3, 4, 5), (6, 7, 8)])}])
+
+
+def test_bad_input_is_rejected(pkg):
+    f = np.float32
+    with pytest.raises(pkg.CrtError) as e:
+        pkg.build_bvh_host([{"vertices": f([(0, 0, 0), (1, 0, 0), (0, 1, 0)]), "triangles": np.uint32([(0, 1, 3)])}])
+    assert "out of range" in str(e.value)
+
+
+def test_depth_bound_on_adversarial_input(pkg, oracle):
+    """Geometric progression of sizes makes SAH peel one triangle per level; the depth guard must cap at 32."""
+    f = np.float32
+    n = 200
+    s = (1.5 ** np.arange(n, dtype=np.float64) * 1e-6).astype(f)[:60]
+    v = np.concatenate([f([(x, 0, 0), (x * 1.1, 0, 0), (x, x * 0.1, 0)]) for x in s])
+    t = np.arange(3 * len(s), dtype=np.uint32).reshape(-1, 3)
+    nodes, tris, shade, md = pkg.build_bvh_host([{"vertices": v, "triangles": t}])
+    assert md <= 32
+    _compare(pkg, oracle, [{"vertices": v, "triangles": t}])

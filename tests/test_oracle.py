@@ -1,0 +1,254 @@
+"""The CPU oracle against closed-form known answers.  The reference ships no tests, golden images or vectors
+(SURVEY.md section 4), so the pins are: the HLSL source restated by hand here in numpy/float32 for chosen inputs
+(rayGen, miss, the 7 closest-hit modes, UNORM store), analytically known scenes, and brute force == BVH."""
+import math
+
+import numpy as np
+import pytest
+
+f32 = np.float32
+IDENT = np.eye(3, dtype=np.float32).reshape(9)
+
+
+# ---------------------------------------------------------------------------------------------- rayGen
+def _raygen_np(rot, px, py, w, h):
+    """hlsl:21-55 in float64 (tolerance compare)."""
+    x = (px + 0.5) / w
+    y = (py + 0.5) / h
+    x = 2 * x - 1
+    y = 1 - 2 * y
+    x *= w / h
+    d = np.array([x, y, -1.0])
+    d /= np.linalg.norm(d)
+    dw = np.asarray(rot, dtype=np.float64).reshape(3, 3) @ d
+    return dw / np.linalg.norm(dw)
+
+
+def test_raygen_identity_camera(oracle):
+    w, h = 1920, 1080
+    for px, py in ((0, 0), (1919, 0), (0, 1079), (1919, 1079), (959, 539), (960, 540), (17, 803)):
+        d = oracle.ray_dir(IDENT, px, py, w, h)
+        np.testing.assert_allclose(d, _raygen_np(IDENT, px, py, w, h), rtol=0, atol=2e-7)
+        assert abs(float(np.linalg.norm(d.astype(np.float64))) - 1.0) < 2e-7
+    # centre pixels straddle the optical axis symmetrically and look down -Z (identity camera, hlsl:46)
+    a, b = oracle.ray_dir(IDENT, 959, 539, w, h), oracle.ray_dir(IDENT, 960, 540, w, h)
+    assert a[2] < -0.999 and a[0] == -b[0] and a[1] == -b[1]
+    # fixed 90 degree vertical field of view: top row's centre is half a pixel inside tan = 1
+    top = oracle.ray_dir(IDENT, 959, 0, w, h)
+    assert abs(top[1] / -top[2] - (1 - 1 / h)) < 1e-6
+    # horizontal extent scaled by the aspect ratio (hlsl:44)
+    right = oracle.ray_dir(IDENT, 1919, 539, w, h)
+    assert abs(right[0] / -right[2] - (w / h) * (1 - 1 / w)) < 1e-6
+
+
+def test_raygen_uses_column_vector_convention(oracle, scenes):
+    """dirWorld = R * dirCam with R's columns right/up/forward (R/DXRTRenderer.cpp:259-264, R/CRTCamera.cpp:81-86):
+    a yawed camera's centre ray is -forward = -(column 2)."""
+    rot = scenes.camera_matrix(30.0, 10.0)
+    d = 0.5 * (oracle.ray_dir(rot, 959, 539, 1920, 1080) + oracle.ray_dir(rot, 960, 540, 1920, 1080))
+    fwd = rot.reshape(3, 3)[:, 2]
+    np.testing.assert_allclose(d / np.linalg.norm(d), -fwd, rtol=0, atol=1e-6)
+    for px, py in ((3, 7), (1900, 1000)):
+        np.testing.assert_allclose(oracle.ray_dir(rot, px, py, 1920, 1080), _raygen_np(rot, px, py, 1920, 1080), rtol=0, atol=3e-7)
+
+
+# ------------------------------------------------------------------------------------------------ sin
+def test_sin_contract_accuracy(oracle):
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-10, 10, 2000), rng.uniform(0, 1.4e7, 2000), rng.uniform(0, 5.6e10, 2000),
+                         [0.0, 12.9898, 78.233, 4014 * 12.9898]]).astype(np.float32)
+    for x in xs:
+        got = oracle.sinf(x)
+        ref = math.sin(float(x))  # the float value x exactly, in double
+        ulp = np.spacing(np.float32(abs(ref))) if ref != 0 else 1e-45
+        assert abs(got - ref) <= 1.0 * float(ulp) + 1e-12, (x, got, ref)
+    assert oracle.sinf(0.0) == 0.0
+
+
+# -------------------------------------------------------------------------------------------- shading
+def _frac(x):
+    return f32(x) - f32(np.floor(f32(x)))
+
+
+def _hash_sin(oracle, x, k):
+    return _frac(f32(f32(oracle.sinf(f32(x))) * f32(k)))
+
+
+def test_mode0_random_triangle_colour(oracle):
+    o, d = (0, 0, 0), (0, 0, -1)
+    for prim in (0, 1, 2, 4013, 1002527):
+        got = oracle.shade_mode(0, 0, prim, 1.0, 0.2, 0.3, o, d)
+        fp = f32(prim)
+        exp = [_hash_sin(oracle, fp * f32(k), 43758.5453) for k in (12.9898, 78.233, 45.164)]
+        np.testing.assert_array_equal(got, f32(exp))
+        assert np.all(got >= 0) and np.all(got < 1)
+    np.testing.assert_array_equal(oracle.shade_mode(0, 5, 0, 1.0, 0, 0, o, d), f32([0, 0, 0]))  # sin(0) = 0
+
+
+def test_mode1_object_cells(oracle):
+    o, d, t = f32([1.0, 2.0, 3.0]), f32([0.6, 0.0, -0.8]), f32(7.5)
+    got = oracle.shade_mode(1, 1, 99, t, 0, 0, o, d)
+    wp = o + d * t
+    cell = np.floor(wp / f32(2.0)).astype(np.int64)
+    h = ((int(cell[0]) * 73856093) & 0xFFFFFFFF) ^ ((int(cell[1]) * 19349663) & 0xFFFFFFFF) ^ ((int(cell[2]) * 83492791) & 0xFFFFFFFF)
+    var = _hash_sin(oracle, f32(np.uint32(h)) * f32(12.9898), 43758.5453)
+    base = [_hash_sin(oracle, f32(1) * f32(12.9898), 43758.5453), _hash_sin(oracle, f32(1) * f32(78.233), 12345.6789),
+            _hash_sin(oracle, f32(1) * f32(39.425), 34567.8901)]
+    exp = [f32(b * f32(0.7)) + var * (f32(b * f32(1.3)) - f32(b * f32(0.7))) for b in base]
+    np.testing.assert_allclose(got, f32(exp), rtol=0, atol=1e-7)
+    # negative cells wrap like uint32 arithmetic (the HLSL multiplies signed ints that overflow, hlsl:107)
+    got2 = oracle.shade_mode(1, 0, 0, f32(50.0), 0, 0, f32([-3, -1, 0]), f32([-0.6, -0.64, -0.48]))
+    assert np.all(np.isfinite(got2))
+
+
+def test_mode2_object_triangle(oracle):
+    got = oracle.shade_mode(2, 1, 77, 3.0, 0.1, 0.1, (0, 0, 0), (0, 0, -1))
+    base = [_hash_sin(oracle, f32(1) * f32(12.9898), 43758.5453), _hash_sin(oracle, f32(1) * f32(78.233), 12345.6789),
+            _hash_sin(oracle, f32(1) * f32(39.425), 34567.8901)]
+    shade = _hash_sin(oracle, f32(77) * f32(12.9898), 43758.5453)
+    k = f32(0.6) + shade * (f32(1.0) - f32(0.6))
+    np.testing.assert_allclose(got, f32([b * k for b in base]), rtol=0, atol=1e-7)
+
+
+def test_mode3_barycentrics(oracle):
+    got = oracle.shade_mode(3, 0, 0, 1.0, 0.25, 0.5, (0, 0, 0), (0, 0, -1))
+    np.testing.assert_array_equal(got, f32([0.25, 0.25, 0.5]))
+
+
+def test_mode4_height(oracle):
+    for y, exp_h in ((-10.0, 0.0), (10.0, 1.0), (0.0, 0.5), (-30.0, 0.0), (50.0, 1.0)):
+        got = oracle.shade_mode(4, 0, 0, 1.0, 0, 0, (0, y + 1.0, 0), (0, -1, 0))
+        exp = [f32(a) + f32(exp_h) * (f32(0.9) - f32(a)) for a in (0.1, 0.2, 0.6)]
+        np.testing.assert_allclose(got, f32(exp), rtol=0, atol=1e-7)
+
+
+def test_mode5_distance(oracle):
+    for t, c in ((0.0, 0.0), (10.0, 0.5), (20.0, 1.0), (400.0, 1.0)):
+        np.testing.assert_allclose(oracle.shade_mode(5, 0, 0, t, 0, 0, (0, 0, 0), (0, 0, -1)), f32([c] * 3), atol=1e-7)
+
+
+def test_mode6_checker_and_fallthrough(oracle):
+    for (x, z), c in (((0.5, 0.5), 0.2), ((1.5, 0.5), 0.9), ((-0.5, 0.5), 0.9), ((-0.5, -0.5), 0.2), ((2.5, 1.5), 0.9)):
+        got = oracle.shade_mode(6, 0, 0, 1.0, 0, 0, (x, 1.0, z), (0, -1, 0))
+        np.testing.assert_array_equal(got, f32([c] * 3))
+    np.testing.assert_array_equal(oracle.shade_mode(42, 0, 0, 1.0, 0, 0, (1.5, 1, 0.5), (0, -1, 0)), f32([0.9] * 3))
+
+
+def test_unorm8_store(oracle):
+    assert [oracle.unorm8(c) for c in (0.0, 1.0, -0.5, 2.0, float("nan"), 0.5, 0.2, 0.9)] == [0, 255, 0, 255, 0, 128, 51, 230]
+    assert oracle.unorm8(1.3 * 0.9) == 255  # mode 1 can exceed 1 -> clamped by the UNORM store
+
+
+# --------------------------------------------------------------------------------------- intersection
+def test_moeller_trumbore_known_answers(oracle):
+    v0, v1, v2 = (-1, -1, -3), (1, -1, -3), (0, 1, -3)
+    hit, t, u, v = oracle.intersect_tri((0, -1 / 3, 0), (0, 0, -1), v0, v1, v2)
+    assert hit and abs(t - 3) < 1e-6 and abs(u - 1 / 3) < 1e-6 and abs(v - 1 / 3) < 1e-6  # centroid
+    hit, t, u, v = oracle.intersect_tri((0, -1 / 3, -6), (0, 0, 1), v0, v1, v2)
+    assert hit and abs(t - 3) < 1e-6  # back face hits too: no culling (R/DXRTRenderer.cpp:590,697-699)
+    assert not oracle.intersect_tri((2, 2, 0), (0, 0, -1), v0, v1, v2)[0]
+    assert not oracle.intersect_tri((0, 0, 0), (1, 0, 0), v0, v1, v2)[0]            # parallel: det == 0
+    assert not oracle.intersect_tri((0, 0, -2.9995), (0, 0, -1), v0, v1, v2)[0]     # t = 0.0005 < TMin (exclusive)
+    assert not oracle.intersect_tri((0, 0, 0), (0, 0, -1), v0, v1, v2, tmax=3.0)[0]  # t == TMax excluded
+    hit, t, u, v = oracle.intersect_tri((1, -1, 0), (0, 0, -1), v0, v1, v2)          # exactly on vertex v1
+    assert hit and u == 1.0 and v == 0.0
+    assert not oracle.intersect_tri((0, 0, 0), (0, 0, -1), (0, 0, -3), (0, 0, -3), (0, 0, -3))[0]  # degenerate
+
+
+# ------------------------------------------------------------------------------ analytically known scenes
+def test_single_triangle_scene(oracle, scenes):
+    sc = scenes.single_triangle(64, 64)
+    S = oracle.OracleScene(sc["meshes"])
+    out = S.render((0, 0, 0), IDENT, 3, 64, 64)
+    hit = out["hit_inst"] != oracle.MISS
+    # rasterise analytically: pixel centre -> point on z=-3 plane -> inside test
+    ys, xs = np.mgrid[0:64, 0:64]
+    X = (2 * (xs + 0.5) / 64 - 1) * 3.0
+    Y = (1 - 2 * (ys + 0.5) / 64) * 3.0
+    inside = (Y >= -1) & (Y <= 1) & (np.abs(X) <= (1 - Y) / 2)
+    edge = np.abs(np.abs(X) - (1 - Y) / 2) < 1e-4
+    assert np.array_equal(hit[~edge], inside[~edge])
+    assert hit.sum() > 100
+    assert np.all(out["hit_prim"][hit] == 0) and np.all(out["hit_inst"][hit] == 0)
+    np.testing.assert_array_equal(out["rgba8"][~hit], np.broadcast_to(np.uint8([0, 255, 255, 255]), (int((~hit).sum()), 4)))  # miss = cyan
+    np.testing.assert_allclose(out["rgb"][hit].sum(axis=1), 1.0, atol=1e-6)  # barycentrics sum to 1
+    assert np.all(out["rgba8"][..., 3] == 255)
+
+
+def test_dragon_ground_plane_closed_form(oracle, dragon):
+    """Pixels whose closest hit is the ground quad (instance 0, y = -5): t and the colours of modes 4,5,6 depend only
+    on the plane, so they are checkable without any BVH (SURVEY.md section 8c iii)."""
+    S = oracle.OracleScene(dragon["meshes"])
+    cam = dragon["camera"]
+    w, h = 480, 270
+    outs = {m: S.render(cam["position"], cam["matrix"], m, w, h) for m in (4, 5, 6)}
+    ground = outs[4]["hit_inst"] == 0
+    assert ground.sum() > 5000
+    ys, xs = np.nonzero(ground)
+    d = np.array([_raygen_np(cam["matrix"], x, y, w, h) for x, y in zip(xs[::97], ys[::97])])
+    t_exact = (-5.0 - float(cam["position"][1])) / d[:, 1]
+    np.testing.assert_allclose(outs[4]["hit_t"][ys[::97], xs[::97]], t_exact, rtol=2e-6)
+    wp = np.asarray(cam["position"], dtype=np.float64) + d * t_exact[:, None]
+    hgt = np.clip((wp[:, 1] + 10) / 20, 0, 1)
+    exp4 = np.stack([a + hgt * (0.9 - a) for a in (0.1, 0.2, 0.6)], axis=1)
+    np.testing.assert_allclose(outs[4]["rgb"][ys[::97], xs[::97]], exp4, atol=1e-5)
+    np.testing.assert_allclose(outs[5]["rgb"][ys[::97], xs[::97], 0], np.clip(t_exact * 0.05, 0, 1), atol=1e-5)
+    fx, fz = wp[:, 0] - np.floor(wp[:, 0]), wp[:, 2] - np.floor(wp[:, 2])
+    safe = (np.minimum(fx, 1 - fx) > 1e-3) & (np.minimum(fz, 1 - fz) > 1e-3)  # away from checker edges
+    chk = (np.floor(wp[:, 0]).astype(np.int64) ^ np.floor(wp[:, 2]).astype(np.int64)) & 1
+    np.testing.assert_allclose(outs[6]["rgb"][ys[::97], xs[::97], 0][safe], np.where(chk, 0.9, 0.2)[safe], atol=1e-6)
+
+
+# ---------------------------------------------------------------------------------- BVH path pinned by brute force
+@pytest.mark.parametrize("name", ["cornell", "dragon", "sphere_small"])
+@pytest.mark.parametrize("mode", [3, 100])
+def test_bvh_equals_brute_force(oracle, scenes, dragon, name, mode):
+    if name == "cornell":
+        sc, (w, h) = scenes.cornell_box(), (128, 128)
+    elif name == "dragon":
+        sc, (w, h) = dragon, (160, 90)
+    else:
+        sc, (w, h) = scenes.displaced_sphere(24, 24), (96, 54)
+    if name == "dragon":
+        sc = dict(sc)
+        sc["meshes"] = [dict(m, normals=scenes.vertex_normals(m["vertices"], m["triangles"])) for m in sc["meshes"]]
+    S = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    cam = sc["camera"]
+    a = S.render(cam["position"], cam["matrix"], mode, w, h)
+    b = S.render(cam["position"], cam["matrix"], mode, w, h, brute_force=True)
+    for k in ("hit_inst", "hit_prim", "hit_t", "rgb", "rgba8"):
+        assert np.array_equal(a[k], b[k], equal_nan=True), k
+    assert a["stats"]["rays_shadow"] == b["stats"]["rays_shadow"]
+    assert a["stats"]["tris_tested"] < b["stats"]["tris_tested"]
+
+
+def test_equal_t_tie_break_is_lowest_global_triangle(oracle):
+    """Two coincident triangles in two meshes: DXR leaves the winner implementation-defined; the spec picks the lower
+    global ordinal, independent of BVH order."""
+    v = f32([(-1, -1, -3), (1, -1, -3), (0, 1, -3)])
+    for order in (0, 1):
+        meshes = [{"vertices": v, "triangles": [(0, 1, 2)]}, {"vertices": v, "triangles": [(0, 1, 2)]},
+                  {"vertices": v + f32([5, 0, 0]), "triangles": [(0, 1, 2)]}]
+        S = oracle.OracleScene(meshes)
+        for bf in (False, True):
+            out = S.render((0, 0, 0), IDENT, 3, 32, 32, brute_force=bf)
+            hit = out["hit_inst"] != oracle.MISS
+            assert hit.any() and np.all(out["hit_inst"][hit & (out["hit_inst"] < 2)] == 0)
+
+
+def test_rows_subset_and_threads(oracle, scenes):
+    sc = scenes.cornell_box()
+    S = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    cam = sc["camera"]
+    full = S.render(cam["position"], cam["matrix"], 100, 64, 64, n_threads=1)
+    part = S.render(cam["position"], cam["matrix"], 100, 64, 64, rows=(3, 64, 8), n_threads=2)
+    rows = np.arange(3, 64, 8)
+    np.testing.assert_array_equal(part["rgba8"][rows], full["rgba8"][rows])
+    assert part["stats"]["rays_primary"] == len(rows) * 64
+    assert np.all(part["rgba8"][0] == 0)
+
+
+def test_empty_scene_is_all_miss(oracle):
+    S = oracle.OracleScene([])
+    out = S.render((0, 0, 0), IDENT, 0, 8, 8)
+    assert np.all(out["hit_inst"] == oracle.MISS) and np.all(out["rgba8"] == np.uint8([0, 255, 255, 255]))

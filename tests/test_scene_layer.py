@@ -1,0 +1,155 @@
+"""Host scene layer (crt::Scene / Camera / Mesh behind crt_scene_*) against known answers produced by the
+reference's own CRT* sources (tests/golden/dragon_scene_layer.json, made by oracle/make_golden.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+REF_DRAGON = "/root/reference/DirectX-RayTracer/DirectX-RayTracer/Scenes/Dragon.crtscene"
+
+
+@pytest.fixture(scope="module")
+def gold(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "dragon_scene_layer.json")))
+
+
+@pytest.fixture(scope="module")
+def scene(pkg, golden_dir):
+    return pkg.Scene(os.path.join(golden_dir, "dragon.crtscene"))
+
+
+def test_record_sizes_pinned_by_reference(gold, pkg):
+    # sizeof(CRTVector)=12, sizeof(CRTMatrix)=36, sizeof(CRTTriangle)=48: static_assert'ed in csrc/scene.h
+    assert gold["sizeof"] == {"CRTVector": 12, "CRTMatrix": 36, "CRTTriangle": 48}
+    text = open(os.path.join(os.path.dirname(pkg.LIB_PATH), "csrc", "scene.h")).read()
+    for s in ("sizeof(Vector) == 12", "sizeof(Matrix) == 36", "sizeof(Triangle) == 48"):
+        assert s in text
+
+
+def test_parse_counts_and_settings(scene, gold):
+    assert scene.mesh_count == len(gold["meshes"]) == 2
+    for i, gm in enumerate(gold["meshes"]):
+        m = scene.mesh(i)
+        assert len(m["vertices"]) == gm["n_vertices"] and m["triangles"].size == gm["n_indices"]
+        assert m["material_index"] == gm["material_index"]
+        np.testing.assert_allclose(m["vertices"].astype(np.float64).sum(axis=0), gm["vertex_sum"], rtol=0, atol=1e-9)
+        assert int(m["triangles"].astype(np.int64).sum()) == gm["index_sum"]
+    st = scene.settings()
+    assert (st["width"], st["height"]) == (gold["settings"]["width"], gold["settings"]["height"])
+    np.testing.assert_array_equal(np.float32(st["background_color"]), np.float32(gold["settings"]["background_color"]))
+    assert scene.texture_count == gold["n_textures"] == 0
+
+
+def test_lights_and_materials(scene, gold):
+    lights = scene.lights()
+    assert len(lights) == len(gold["lights"]) == 4
+    for (pos, inten), g in zip(lights, gold["lights"]):
+        np.testing.assert_array_equal(np.float32(pos), np.float32(g["position"]))
+        assert np.float32(inten) == np.float32(g["intensity"])
+    mats = scene.materials()
+    assert len(mats) == 2
+    for m, g in zip(mats, gold["materials"]):
+        assert m["type"] == g["type"] and m["smooth_shading"] == bool(g["smooth_shading"])
+        np.testing.assert_array_equal(np.float32(m["albedo"]), np.float32(g["albedo"]))
+
+
+def test_vertex_normals_match_reference(scene, gold):
+    """CRTMesh::calculateVertexNormals (R/CRTMesh.cpp:66-94), 2 012 normals, bit-exact."""
+    for i, gm in enumerate(gold["meshes"]):
+        n = scene.mesh(i)["normals"]
+        ref = np.array(gm["vertex_normals"], dtype=np.float32)
+        assert n.shape == ref.shape
+        np.testing.assert_array_equal(n, ref)
+
+
+def test_camera_initial(scene, gold):
+    pos, rot = scene.camera()
+    np.testing.assert_array_equal(pos, np.float32(gold["camera"]["position"]))
+    np.testing.assert_array_equal(rot, np.float32(gold["camera"]["matrix"]))
+
+
+def test_camera_operation_sequence(pkg, golden_dir, gold):
+    """CRTCamera::rotate/zoom/moveForward/moveRight/pan/tilt/roll/panAroundTarget (R/CRTCamera.cpp:9-130),
+    including both pitch clamps, state after every step against the reference's values."""
+    s = pkg.Scene(os.path.join(golden_dir, "dragon.crtscene"))
+    ops = [lambda: None, lambda: s.rotate(10.0, 5.0), lambda: s.zoom(2.5), lambda: s.move_forward(-1.25),
+           lambda: s.move_right(3.0), lambda: s.rotate(-35.0, -120.0), lambda: s.rotate(200.0, 300.0),
+           lambda: s.move_forward(0.5), lambda: s.pan(30.0), lambda: s.tilt(-12.0), lambda: s.roll(7.0),
+           lambda: s.pan_around_target(45.0, (0.0, 0.0, 0.0))]
+    assert len(ops) == len(gold["camera_sequence"])
+    for op, g in zip(ops, gold["camera_sequence"]):
+        op()
+        pos, rot = s.camera()
+        np.testing.assert_allclose(pos, np.float32(g["position"]), rtol=0, atol=2e-6, err_msg=g["op"])
+        np.testing.assert_allclose(rot, np.float32(g["matrix"]), rtol=0, atol=2e-7, err_msg=g["op"])
+
+
+def test_python_vertex_normals_helper_matches(scenes, dragon, gold):
+    n = scenes.vertex_normals(dragon["meshes"][1]["vertices"], dragon["meshes"][1]["triangles"])
+    np.testing.assert_allclose(n, np.array(gold["meshes"][1]["vertex_normals"], dtype=np.float32), rtol=0, atol=1e-6)
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DRAGON), reason="reference tree not mounted (GPU box)")
+def test_original_scene_file_parses_to_the_same_data(pkg, scene):
+    """The reference's shipped Dragon.crtscene, read in place, gives the same arrays as the re-serialised fixture."""
+    orig = pkg.Scene(REF_DRAGON)
+    assert orig.mesh_count == scene.mesh_count
+    for i in range(orig.mesh_count):
+        a, b = orig.mesh(i), scene.mesh(i)
+        np.testing.assert_array_equal(a["vertices"], b["vertices"])
+        np.testing.assert_array_equal(a["triangles"], b["triangles"])
+        np.testing.assert_array_equal(a["normals"], b["normals"])
+    assert orig.lights() == scene.lights() and orig.materials() == scene.materials()
+    assert orig.settings() == scene.settings()
+
+
+def test_absent_keys_take_defaults(pkg, tmp_path):
+    """Keys the reference dereferences when absent (uvs, textures, material_index, smooth_shading, ior) default here."""
+    p = tmp_path / "min.crtscene"
+    p.write_text('{"objects":[{"vertices":[0,0,0, 1,0,0, 0,1,0],"triangles":[0,1,2]}],'
+                 '"materials":[{"type":"glass"},{"type":"diffuse","albedo":"checker_tex"}],'
+                 '"textures":[{"name":"checker_tex","type":"checker","color_A":[1,0,0],"color_B":[0,0,1],"square_size":0.25}]}')
+    s = pkg.Scene(str(p))
+    assert s.mesh_count == 1 and s.mesh(0)["material_index"] == 0
+    mats = s.materials()
+    assert mats[0]["type"] == 3 and mats[0]["ior"] == 1.0 and mats[0]["albedo"] == (1.0, 1.0, 1.0) and not mats[0]["smooth_shading"]
+    assert mats[1]["type"] == 1
+    assert s.texture_count == 1
+    pos, rot = s.camera()
+    np.testing.assert_array_equal(rot, np.eye(3, dtype=np.float32).reshape(9))
+    np.testing.assert_array_equal(s.mesh(0)["normals"], np.float32([[0, 0, 1]] * 3))
+
+
+def test_parse_errors_are_reported_not_asserted(pkg, tmp_path):
+    with pytest.raises(pkg.CrtError) as e:
+        pkg.Scene(str(tmp_path / "missing.crtscene"))
+    assert "rc=6" in str(e.value)  # CRT_EIO
+    bad = tmp_path / "bad.crtscene"
+    bad.write_text('{"objects":[{"vertices":[0,0,0],"triangles":[0,1,2]}]}')
+    with pytest.raises(pkg.CrtError) as e:
+        pkg.Scene(str(bad))
+    assert "rc=7" in str(e.value) and "out of range" in str(e.value)
+    bad.write_text('{"objects": [')
+    with pytest.raises(pkg.CrtError):
+        pkg.Scene(str(bad))
+
+
+def test_obj_loader(pkg, tmp_path):
+    p = tmp_path / "quad.obj"
+    p.write_text("# quad + tri\nv 0 0 0\nv 1 0 0\nv 1 1 0\nv 0 1 0\nf 1 2 3 4\no second\nv 0 0 1\nv 1 0 1\nv 0 1 1\nf -3/1/1 -2/2/2 -1/3/3\n")
+    s = pkg.Scene(str(p))
+    assert s.mesh_count == 2
+    a, b = s.mesh(0), s.mesh(1)
+    assert len(a["vertices"]) == 4 and a["triangles"].tolist() == [[0, 1, 2], [0, 2, 3]]
+    assert len(b["vertices"]) == 3 and b["triangles"].tolist() == [[0, 1, 2]]
+    np.testing.assert_array_equal(b["vertices"][:, 2], np.float32([1, 1, 1]))
+    assert len(s.materials()) == 1
+
+
+def test_programmatic_scene_roundtrip(pkg, scenes):
+    sc = scenes.cornell_box()
+    s = pkg.Scene.from_arrays(sc)
+    assert s.mesh_count == 6 and sum(len(m["triangles"]) for m in s.meshes()) == 32
+    pos, rot = s.camera()
+    np.testing.assert_array_equal(pos, sc["camera"]["position"])
