@@ -31,16 +31,28 @@ W, H = 1920, 1080
 MODE = 100  # Lambert + one shadow ray per light
 
 
+def usable_cores(omp_default):
+    """threads the host really gives this process: affinity mask and cgroup CPU quota (the GPU box grants a share)"""
+    n = min(omp_default, len(os.sched_getaffinity(0)))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period) + 0.5)))
+    except (OSError, ValueError):
+        pass
+    return max(1, n)
+
+
 def cpu_baseline(oracle, sc, budget_s=10.0):
     """CPU restatement (the build's own oracle, NOT reference code: the reference has no CPU renderer) of the same
     workload on this host's cores: same scene, same BVH, same arithmetic; OpenMP over image rows."""
     cam = sc["camera"]
     O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
-    cores = oracle.max_threads()
-    O.render(cam["position"], cam["matrix"], MODE, W, H, want=("rgba8",))  # warm caches / thread pool
+    cores = usable_cores(oracle.max_threads())
+    O.render(cam["position"], cam["matrix"], MODE, W, H, want=("rgba8",), n_threads=cores)  # warm caches / thread pool
     frames, rays, t0 = 0, 0, time.perf_counter()
     while True:
-        st = O.render(cam["position"], cam["matrix"], MODE, W, H, want=("rgba8",))["stats"]
+        st = O.render(cam["position"], cam["matrix"], MODE, W, H, want=("rgba8",), n_threads=cores)["stats"]
         frames += 1
         rays += st["rays_primary"] + st["rays_shadow"]
         dt = time.perf_counter() - t0
@@ -152,7 +164,7 @@ def main():
     # PCIe-inclusive variant (host output buffer handed over the C ABI), for DESIGN.md; never `value`
     d2h_ms = None
     if world == 1:
-        r.set_stream(None)
+        r.reset_stream()
         r.render_frame(W, H, want=())
         t0 = time.perf_counter()
         for _ in range(5):

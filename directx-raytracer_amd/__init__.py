@@ -31,7 +31,7 @@ SHADE_DTYPE = np.dtype([("n0", "f4", 3), ("n1", "f4", 3), ("n2", "f4", 3), ("mat
 ABI_SYMBOLS = [
     "crt_abi_version", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
     "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_render_frame", "crt_render_frame_device",
-    "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_untile_device", "crt_set_stream",
+    "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_untile_device", "crt_set_stream", "crt_reset_stream",
     "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free",
     "crt_scene_load", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
     "crt_scene_add_material", "crt_scene_mesh_count", "crt_scene_mesh", "crt_scene_light_count", "crt_scene_light",
@@ -87,6 +87,13 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise CrtError("libcrt_hip.so is missing (%s): run __graft_entry__.build() / make -C csrc; "
                        "there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: libcrt_hip.so needs libamdhip64.so.7 and takes whichever copy the process has
+    # already loaded.  PyTorch bundles its own (torch/lib, same SONAME); if ours (/opt/rocm) were loaded first torch
+    # would end up with a mixed runtime and report "No HIP GPUs".  So when torch is around, let it load first.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, u32, i32, f32 = C.c_void_p, C.c_uint32, C.c_int32, C.c_float
     sig = {
@@ -106,6 +113,7 @@ def lib():
         "crt_render_tiles_device": (C.c_int, [vp, u32, u32, u32, u32, vp, vp]),
         "crt_untile_device": (C.c_int, [vp, u32, u32, u32, vp, vp]),
         "crt_set_stream": (C.c_int, [vp, vp]),
+        "crt_reset_stream": (C.c_int, [vp]),
         "crt_synchronize": (C.c_int, [vp]),
         "crt_bvh_info": (C.c_int, [vp, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]),
         "crt_bvh_export": (C.c_int, [vp, vp, vp, vp]),
@@ -438,7 +446,11 @@ class Renderer:
         self._ok(lib().crt_set_counting(self.h, int(bool(on))), "crt_set_counting")
 
     def set_stream(self, stream_ptr):
+        """run on an external hipStream_t handle (0 / None = HIP's default stream, which is torch's default)"""
         self._ok(lib().crt_set_stream(self.h, stream_ptr), "crt_set_stream")
+
+    def reset_stream(self):
+        self._ok(lib().crt_reset_stream(self.h), "crt_reset_stream")
 
     def synchronize(self):
         self._ok(lib().crt_synchronize(self.h), "crt_synchronize")

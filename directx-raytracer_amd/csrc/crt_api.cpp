@@ -313,7 +313,14 @@ int crt_set_counting(crt_ctx* c, int enabled)
 int crt_set_stream(crt_ctx* c, void* hip_stream)
 {
     if (!c) return CRT_EINVAL;
-    c->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : c->ownStream;
+    c->stream = static_cast<hipStream_t>(hip_stream);
+    return CRT_OK;
+}
+
+int crt_reset_stream(crt_ctx* c)
+{
+    if (!c) return CRT_EINVAL;
+    c->stream = c->ownStream;
     return CRT_OK;
 }
 

@@ -138,8 +138,10 @@ int crt_render_tiles_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint3
 int crt_untile_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_ranks,
                       const void* d_gathered, void* d_rgba8_rowmajor);
 
-/* stream plumbing: use an external hipStream_t (e.g. torch's current stream); NULL restores the own stream */
+/* stream plumbing: run on an external hipStream_t (e.g. torch's current stream; NULL = HIP's default stream);
+ * crt_reset_stream goes back to the context's private non-blocking stream */
 int crt_set_stream(crt_ctx* ctx, void* hip_stream);
+int crt_reset_stream(crt_ctx* ctx);
 int crt_synchronize(crt_ctx* ctx);
 
 /* BVH introspection (tests, tooling): sizes, then copies of the host-side arrays uploaded to HBM */

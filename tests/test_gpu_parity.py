@@ -189,7 +189,7 @@ def test_external_stream_and_error_paths(pkg, scenes, renderer):
     r2.render_frame_device(64, 64, buf.data_ptr())
     a = buf.clone()
     torch.cuda.synchronize()
-    r2.set_stream(None)
+    r2.reset_stream()
     ref = r2.render_frame(64, 64)["rgba8"].view(np.uint32).reshape(-1)
     assert np.array_equal(a.cpu().numpy().view(np.uint32), ref)
     r2.close()
