@@ -47,6 +47,8 @@ struct crt_ctx {
     float miss[3] = { 0.f, 1.f, 1.f }; // hlsl:75
     uint32_t mode = 0;                 // R/DXRTRenderer.h:246 default shading mode
     bool counting = false;
+    uint32_t tuneInnerMin = 24;    // wave scheduling threshold of the traversal loop (render_kernels.hip)
+    uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
     unsigned long long* dCounters = nullptr;
 
     // scratch frame buffers for the host-output path, grown on demand
@@ -124,6 +126,11 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     const uint32_t nTiles = p.tiles_x * p.tiles_y;
     p.n_local_tiles = rank < nTiles ? (nTiles - rank + nRanks - 1) / nRanks : 0;
     p.counters = c->dCounters;
+    p.tune_inner_min = c->tuneInnerMin;
+    // a ray's stack never holds more entries than the tree is deep; fewer entries = less LDS = more resident waves
+    uint32_t need = c->bvh.maxDepth < 4 ? 4 : c->bvh.maxDepth;
+    need = (need + 1u) & ~1u;
+    p.stack_entries = c->tuneStackEntries ? c->tuneStackEntries : (need > crt::kStackEntries ? crt::kStackEntries : need);
 }
 
 // enqueue one frame; when stats != nullptr, bracket with events, synchronise and fill the timers/counters
@@ -308,6 +315,20 @@ int crt_set_counting(crt_ctx* c, int enabled)
     if (!c) return CRT_EINVAL;
     c->counting = enabled != 0;
     return CRT_OK;
+}
+
+int crt_set_option(crt_ctx* c, const char* name, int value)
+{
+    if (!c || !name) return CRT_EINVAL;
+    if (std::strcmp(name, "inner_min") == 0 && value >= 1 && value <= 65) {
+        c->tuneInnerMin = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "stack_entries") == 0 && (value == 0 || (value >= static_cast<int>(c->bvh.maxDepth) && value <= crt::kStackEntries))) {
+        c->tuneStackEntries = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    return fail(c, CRT_EINVAL, "unknown option '%s' or value %d out of range", name, value);
 }
 
 int crt_set_stream(crt_ctx* c, void* hip_stream)

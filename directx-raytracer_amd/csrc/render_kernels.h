@@ -8,7 +8,7 @@ struct ihipStream_t;
 namespace crt {
 
 constexpr int kTile = 16;          // macro tile edge: one 256-thread workgroup = 4 wavefronts of 8x8 pixels
-constexpr int kStackEntries = 32;  // per-lane LDS traversal stack = kMaxDepth of the builder
+constexpr int kStackEntries = 32;  // upper bound of the per-lane LDS traversal stack = kMaxDepth of the builder
 
 struct RenderParams {
     // scene (HBM)
@@ -29,6 +29,8 @@ struct RenderParams {
     uint32_t rank, n_ranks;      // this launch renders macro tiles k with k % n_ranks == rank
     uint32_t n_local_tiles;      // grid size: number of such tiles
     uint32_t staging;            // 0: write row-major frame buffers; 1: rgba8 goes to the tile-major staging buffer
+    uint32_t tune_inner_min;     // wave scheduling knob, see traceClosest()
+    uint32_t stack_entries;      // per-lane LDS stack depth (>= BVH depth, <= kStackEntries)
     // outputs (device pointers, nullable except rgba8)
     uint32_t* rgba8;
     uint32_t* hit_inst;

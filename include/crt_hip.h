@@ -138,6 +138,9 @@ int crt_render_tiles_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint3
 int crt_untile_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_ranks,
                       const void* d_gathered, void* d_rgba8_rowmajor);
 
+/* tuning knobs (speed only, results never change). "inner_min" 1..65: wave scheduling of the traversal loop */
+int crt_set_option(crt_ctx* ctx, const char* name, int value);
+
 /* stream plumbing: run on an external hipStream_t (e.g. torch's current stream; NULL = HIP's default stream);
  * crt_reset_stream goes back to the context's private non-blocking stream */
 int crt_set_stream(crt_ctx* ctx, void* hip_stream);

@@ -44,6 +44,7 @@
 /* ------------------------------------------------------------------------------------------------
  * small math (explicit FMA placement is part of the contract)
  * ---------------------------------------------------------------------------------------------- */
+static _Thread_local int t_max_sp; /* deepest stack of the rays traced by this thread since last reset (analysis only) */
 typedef struct { float x, y, z; } v3;
 
 static inline v3 v3_make(float x, float y, float z) { v3 r = { x, y, z }; return r; }
@@ -436,6 +437,7 @@ static void trace_closest(const oracle_scene* s, const ray* r, float tmin, float
             if (hl & hr) {
                 int right_first = tnr < tnl;
                 stack[sp++] = right_first ? N->left : N->right;
+                if (sp > t_max_sp) t_max_sp = sp;
                 cur = right_first ? N->right : N->left;
                 continue;
             }
@@ -479,6 +481,7 @@ static int trace_any(const oracle_scene* s, const ray* r, float tmin, float tmax
             if (hl & hr) {
                 int right_first = tnr < tnl;
                 stack[sp++] = right_first ? N->left : N->right;
+                if (sp > t_max_sp) t_max_sp = sp;
                 cur = right_first ? N->right : N->left;
                 continue;
             }
@@ -670,6 +673,15 @@ static v3 shade_lambert(const oracle_scene* s, const ray* r, const hit_rec* h, i
     return rgb;
 }
 
+static uint32_t* g_cost_sp;
+static uint32_t *g_cost_pn, *g_cost_pt, *g_cost_sn, *g_cost_st;
+int oracle_debug_max_sp(int reset) { int v = t_max_sp; if (reset) t_max_sp = 0; return v; } /* per-pixel fetch counts (analysis of lane utilisation) */
+void oracle_set_cost_outputs(uint32_t* pn, uint32_t* pt, uint32_t* sn, uint32_t* st)
+{
+    g_cost_pn = pn; g_cost_pt = pt; g_cost_sn = sn; g_cost_st = st;
+}
+void oracle_set_stack_output(uint32_t* max_sp) { g_cost_sp = max_sp; }
+
 int oracle_max_threads(void)
 {
 #ifdef _OPENMP
@@ -706,8 +718,11 @@ int oracle_render(const oracle_scene* s, const float pos[3], const float rot[9],
             ray r;
             hit_rec hr;
             ray_setup(&r, o, ray_dir(rot, px, py, width, height));
+            const trav_count c0 = c;
+            if (g_cost_sp) t_max_sp = 0;
             if (brute_force) brute_closest(s, &r, RAY_TMIN, RAY_TMAX, &hr, &c);
             else trace_closest(s, &r, RAY_TMIN, RAY_TMAX, &hr, &c);
+            const trav_count c1 = c;
             v3 col = miss;
             uint32_t inst = ORACLE_MISS, prim = ORACLE_MISS;
             if (hr.hit) {
@@ -717,6 +732,11 @@ int oracle_render(const oracle_scene* s, const float pos[3], const float rot[9],
                 else col = shade_debug(mode, inst, prim, hr.t, hr.u, hr.v, r.o, r.d);
             }
             const size_t pix = (size_t)py * w + px;
+            if (g_cost_sp) g_cost_sp[pix] = (uint32_t)t_max_sp;
+            if (g_cost_pn) {
+                g_cost_pn[pix] = (uint32_t)(c1.nodes - c0.nodes); g_cost_pt[pix] = (uint32_t)(c1.tris - c0.tris);
+                g_cost_sn[pix] = (uint32_t)(c.nodes - c1.nodes); g_cost_st[pix] = (uint32_t)(c.tris - c1.tris);
+            }
             if (rgba8) {
                 rgba8[4 * pix + 0] = oracle_unorm8(col.x);
                 rgba8[4 * pix + 1] = oracle_unorm8(col.y);

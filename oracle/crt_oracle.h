@@ -99,6 +99,10 @@ uint32_t oracle_scene_max_depth(const oracle_scene* s);
  *   brute_force != 0: closest hit / occlusion by testing every triangle (no BVH) -- pins the BVH path.
  *   n_threads <= 0: OpenMP default.
  */
+/* optional per-pixel instrumentation for the next oracle_render call of the calling thread's process: two w*h uint32
+ * arrays receiving (node fetches << 8 | triangle fetches... ) see crt_oracle.c; pass NULL to disable */
+void oracle_set_cost_outputs(uint32_t* primary_nodes, uint32_t* primary_tris, uint32_t* shadow_nodes, uint32_t* shadow_tris);
+
 int oracle_render(const oracle_scene* s, const float pos[3], const float rot[9], uint32_t mode,
                   const float miss_rgb[3], uint32_t w, uint32_t h,
                   uint32_t y_begin, uint32_t y_end, uint32_t y_step,
