@@ -49,6 +49,7 @@ struct crt_ctx {
     bool counting = false;
     uint32_t tuneInnerMin = 24;    // wave scheduling threshold of the traversal loop (render_kernels.hip)
     uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
+    uint32_t tuneBlockSize = 64;   // 64: one-wavefront workgroups (finer dispatch + LDS granularity, measured 5 % faster than 256)
     unsigned long long* dCounters = nullptr;
 
     // scratch frame buffers for the host-output path, grown on demand
@@ -127,6 +128,7 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.n_local_tiles = rank < nTiles ? (nTiles - rank + nRanks - 1) / nRanks : 0;
     p.counters = c->dCounters;
     p.tune_inner_min = c->tuneInnerMin;
+    p.block_size = c->tuneBlockSize;
     // a ray's stack never holds more entries than the tree is deep; fewer entries = less LDS = more resident waves
     uint32_t need = c->bvh.maxDepth < 4 ? 4 : c->bvh.maxDepth;
     need = (need + 1u) & ~1u;
@@ -322,6 +324,10 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
     if (!c || !name) return CRT_EINVAL;
     if (std::strcmp(name, "inner_min") == 0 && value >= 1 && value <= 65) {
         c->tuneInnerMin = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "block_size") == 0 && (value == 64 || value == 256)) {
+        c->tuneBlockSize = static_cast<uint32_t>(value);
         return CRT_OK;
     }
     if (std::strcmp(name, "stack_entries") == 0 && (value == 0 || (value >= static_cast<int>(c->bvh.maxDepth) && value <= crt::kStackEntries))) {

@@ -31,6 +31,7 @@ struct RenderParams {
     uint32_t staging;            // 0: write row-major frame buffers; 1: rgba8 goes to the tile-major staging buffer
     uint32_t tune_inner_min;     // wave scheduling knob, see traceClosest()
     uint32_t stack_entries;      // per-lane LDS stack depth (>= BVH depth, <= kStackEntries)
+    uint32_t block_size;         // 256 (4 wavefronts per workgroup) or 64 (one)
     // outputs (device pointers, nullable except rgba8)
     uint32_t* rgba8;
     uint32_t* hit_inst;

@@ -134,7 +134,7 @@ struct Hit {
 
 // One traversal step for a lane standing on an inner node: fetch the 64-byte record, test both child boxes,
 // descend into the nearer hit child (far one pushed) or pop.
-template <bool COUNT>
+template <bool COUNT, int BLOCK>
 __device__ __forceinline__ void nodeStep(const float4* __restrict__ nodes, const Ray& r, float tmin, float tcull, int* stack,
                                          int& cur, int& sp, uint32_t& cntNodes)
 {
@@ -147,7 +147,7 @@ __device__ __forceinline__ void nodeStep(const float4* __restrict__ nodes, const
     const bool hr = boxTest(n1.x, n1.y, n1.z, n1.w, n2.z, n2.w, r, tmin, tcull, tnr);
     if (hl & hr) {
         const bool rightFirst = tnr < tnl;
-        stack[sp * kBlock] = rightFirst ? n3.x : n3.y;
+        stack[sp * BLOCK] = rightFirst ? n3.x : n3.y;
         sp++;
         cur = rightFirst ? n3.y : n3.x;
     } else if (hl) {
@@ -158,7 +158,7 @@ __device__ __forceinline__ void nodeStep(const float4* __restrict__ nodes, const
         cur = kDone;
     } else {
         sp--;
-        cur = stack[sp * kBlock];
+        cur = stack[sp * BLOCK];
     }
 }
 
@@ -167,7 +167,7 @@ __device__ __forceinline__ void nodeStep(const float4* __restrict__ nodes, const
 // node steps are issued while at least `innerMin` lanes still stand on inner nodes (or nobody waits at a leaf); then the
 // lanes waiting at leaves intersect their triangles.  innerMin = 1 is the classic while-while loop (leaves wait until
 // every lane has one: 47 % of the lanes active on the 1M-triangle frame); 24 measured best (0.67 vs 1.10 ms).
-template <bool COUNT>
+template <bool COUNT, int BLOCK>
 __device__ __forceinline__ void traceClosest(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                              uint32_t n_nodes, const Ray& r, float tmin, float tmax, int* stack, int innerMin,
                                              Hit& h, uint32_t& cntNodes, uint32_t& cntTris)
@@ -181,7 +181,7 @@ __device__ __forceinline__ void traceClosest(const float4* __restrict__ nodes, c
         const unsigned long long leafMask = __ballot((cur < 0) & (cur != kDone));
         if ((innerMask | leafMask) == 0ull) break;
         if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
-            if (cur >= 0) nodeStep<COUNT>(nodes, r, tmin, tcull, stack, cur, sp, cntNodes);
+            if (cur >= 0) nodeStep<COUNT, BLOCK>(nodes, r, tmin, tcull, stack, cur, sp, cntNodes);
             continue;
         }
         if ((cur < 0) & (cur != kDone)) {
@@ -204,13 +204,13 @@ __device__ __forceinline__ void traceClosest(const float4* __restrict__ nodes, c
                 cur = kDone;
             } else {
                 sp--;
-                cur = stack[sp * kBlock];
+                cur = stack[sp * BLOCK];
             }
         }
     }
 }
 
-template <bool COUNT>
+template <bool COUNT, int BLOCK>
 __device__ __forceinline__ bool traceAny(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                          uint32_t n_nodes, const Ray& r, float tmin, float tmax, int* stack, int innerMin,
                                          uint32_t& cntNodes, uint32_t& cntTris)
@@ -224,7 +224,7 @@ __device__ __forceinline__ bool traceAny(const float4* __restrict__ nodes, const
         const unsigned long long leafMask = __ballot((cur < 0) & (cur != kDone));
         if ((innerMask | leafMask) == 0ull) break;
         if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
-            if (cur >= 0) nodeStep<COUNT>(nodes, r, tmin, tcull, stack, cur, sp, cntNodes);
+            if (cur >= 0) nodeStep<COUNT, BLOCK>(nodes, r, tmin, tcull, stack, cur, sp, cntNodes);
             continue;
         }
         if ((cur < 0) & (cur != kDone)) {
@@ -244,7 +244,7 @@ __device__ __forceinline__ bool traceAny(const float4* __restrict__ nodes, const
                 cur = kDone;
             } else {
                 sp--;
-                cur = stack[sp * kBlock];
+                cur = stack[sp * BLOCK];
             }
         }
     }
@@ -316,7 +316,7 @@ struct LightRec { float x, y, z, intensity; };
 struct MaterialRec { float r, g, b; uint32_t type; uint32_t smooth; float ior; };
 
 // Lambert + one shadow ray per light (mode 100): extension, specified by oracle/crt_oracle.c shade_lambert
-template <bool COUNT>
+template <bool COUNT, int BLOCK>
 __device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* nodes, const float4* tris, const Ray& r,
                                            const Hit& h, int* stack, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
 {
@@ -355,7 +355,7 @@ __device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* 
         if (cosv > 0.0f) {
             const Ray sr = makeRay(Po, Ld);
             if (COUNT) cntShadow++;
-            const bool occluded = traceAny<COUNT>(nodes, tris, p.n_nodes, sr, 0.0f, dist, stack, static_cast<int>(p.tune_inner_min), cntNodes, cntTris);
+            const bool occluded = traceAny<COUNT, BLOCK>(nodes, tris, p.n_nodes, sr, 0.0f, dist, stack, static_cast<int>(p.tune_inner_min), cntNodes, cntTris);
             if (!occluded) {
                 const float k = (L.intensity / (kFourPi * r2)) * cosv;
                 rgb.x = fmaf(albedo.x, k, rgb.x);
@@ -373,8 +373,8 @@ __device__ __forceinline__ uint32_t waveSum(uint32_t v)
     return v;
 }
 
-template <bool COUNT>
-__global__ __launch_bounds__(kBlock) void renderKernel(const RenderParams p)
+template <bool COUNT, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void renderKernel(const RenderParams p)
 {
     extern __shared__ int s_stack[]; // stack_entries x 256 dwords, sized at launch from the BVH depth
 
@@ -382,7 +382,11 @@ __global__ __launch_bounds__(kBlock) void renderKernel(const RenderParams p)
     // The tile list is cut into groups of kGroup consecutive tiles and the groups are dealt round-robin to the XCDs:
     // an XCD's consecutive workgroups stay inside one group (its L2 keeps that group's subtrees) while all XCDs sweep
     // the frame together (sky rows cost nothing, so a contiguous band per XCD would leave most of the chip idle).
-    const uint32_t b = blockIdx.x, xcd = b & 7u, i = b >> 3;
+    // BLOCK = 256: one workgroup per 16x16 macro tile (4 wavefronts). BLOCK = 64: one single-wavefront workgroup per
+    // 8x8 sub-tile, the 4 sub-tiles of a macro tile consecutive on the same XCD (finer dispatch and LDS granularity).
+    const uint32_t b = blockIdx.x, xcd = b & 7u;
+    const uint32_t seq = b >> 3; // position in this XCD's workgroup sequence
+    const uint32_t i = BLOCK == 64 ? seq >> 2 : seq;
     const uint32_t j = ((i / kGroup) * 8u + xcd) * kGroup + (i % kGroup); // position in this rank's tile list
     uint32_t tile_x, tile_y;
     if (p.n_ranks == 1) {
@@ -400,7 +404,7 @@ __global__ __launch_bounds__(kBlock) void renderKernel(const RenderParams p)
         tile_y = k / p.tiles_x;
     }
 
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t tid = threadIdx.x, wave = BLOCK == 64 ? (seq & 3u) : (tid >> 6), lane = tid & 63u;
     const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
     const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
     const bool active = (px < p.width) & (py < p.height);
@@ -414,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void renderKernel(const RenderParams p)
         const F3 o = f3(p.pos[0], p.pos[1], p.pos[2]);
         const Ray r = makeRay(o, rayDir(p.rot, px, py, static_cast<float>(p.width), static_cast<float>(p.height)));
         Hit h;
-        traceClosest<COUNT>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, cntNodes, cntTris);
+        traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, cntNodes, cntTris);
 
         F3 col = f3(p.miss[0], p.miss[1], p.miss[2]); // miss shader (hlsl:72-76)
         uint32_t inst = 0xFFFFFFFFu, prim = 0xFFFFFFFFu;
@@ -423,7 +427,7 @@ __global__ __launch_bounds__(kBlock) void renderKernel(const RenderParams p)
             const float4* T = tris + 3 * static_cast<size_t>(h.tri);
             inst = __float_as_uint(T[0].w);
             prim = __float_as_uint(T[1].w);
-            if (p.mode >= 100u) col = shadeLambert<COUNT>(p, nodes, tris, r, h, stack, cntNodes, cntTris, cntShadow);
+            if (p.mode >= 100u) col = shadeLambert<COUNT, BLOCK>(p, nodes, tris, r, h, stack, cntNodes, cntTris, cntShadow);
             else col = shadeDebug(p.mode, inst, prim, h.t, h.u, h.v, r.o, r.d);
         }
 
@@ -472,10 +476,16 @@ int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream)
     uint32_t n = p.n_local_tiles;
     if (p.n_ranks == 1) n = ((p.tiles_x + 3u) / 4u) * ((p.tiles_y + 3u) / 4u) * 16u;
     n = (n + 8u * kGroup - 1u) / (8u * kGroup) * (8u * kGroup);
-    const dim3 grid(n), block(kBlock);
-    const size_t lds = static_cast<size_t>(p.stack_entries) * kBlock * sizeof(int);
-    if (counting) hipLaunchKernelGGL(renderKernel<true>, grid, block, lds, stream, p);
-    else hipLaunchKernelGGL(renderKernel<false>, grid, block, lds, stream, p);
+    const uint32_t bs = p.block_size == 64 ? 64u : 256u;
+    const dim3 grid(bs == 64 ? n * 4u : n), block(bs);
+    const size_t lds = static_cast<size_t>(p.stack_entries) * bs * sizeof(int);
+    if (bs == 64) {
+        if (counting) hipLaunchKernelGGL((renderKernel<true, 64>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((renderKernel<false, 64>), grid, block, lds, stream, p);
+    } else {
+        if (counting) hipLaunchKernelGGL((renderKernel<true, 256>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((renderKernel<false, 256>), grid, block, lds, stream, p);
+    }
     return static_cast<int>(hipGetLastError());
 }
 
