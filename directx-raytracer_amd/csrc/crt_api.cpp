@@ -49,8 +49,12 @@ struct crt_ctx {
     bool counting = false;
     uint32_t tuneInnerMin = 24;    // wave scheduling threshold of the traversal loop (render_kernels.hip)
     uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
+    uint32_t tuneXcdGroup = 16;
     uint32_t tuneBlockSize = 64;   // 64: one-wavefront workgroups (finer dispatch + LDS granularity, measured 5 % faster than 256)
     unsigned long long* dCounters = nullptr;
+    unsigned long long* dTimeline = nullptr; // diagnostic: 3 words per workgroup, counting variant only
+    size_t timelineWords = 0;
+    bool wantTimeline = false;
 
     // scratch frame buffers for the host-output path, grown on demand
     void* dFrame[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -127,8 +131,10 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     const uint32_t nTiles = p.tiles_x * p.tiles_y;
     p.n_local_tiles = rank < nTiles ? (nTiles - rank + nRanks - 1) / nRanks : 0;
     p.counters = c->dCounters;
+    p.timeline = nullptr;
     p.tune_inner_min = c->tuneInnerMin;
     p.block_size = c->tuneBlockSize;
+    p.xcd_group = c->tuneXcdGroup;
     // a ray's stack never holds more entries than the tree is deep; fewer entries = less LDS = more resident waves
     uint32_t need = c->bvh.maxDepth < 4 ? 4 : c->bvh.maxDepth;
     need = (need + 1u) & ~1u;
@@ -140,6 +146,17 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
 {
     const bool counting = c->counting;
     if (counting) HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 3 * sizeof(unsigned long long), c->stream));
+    if (c->wantTimeline) {
+        const size_t words = 3 * (static_cast<size_t>(p.tiles_x + 4) * (p.tiles_y + 4) * 4 + 1024);
+        if (c->timelineWords < words) {
+            if (c->dTimeline) (void)hipFree(c->dTimeline);
+            c->dTimeline = nullptr;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dTimeline), words * sizeof(unsigned long long)));
+            c->timelineWords = words;
+        }
+        HIP_TRY(c, hipMemsetAsync(c->dTimeline, 0, c->timelineWords * sizeof(unsigned long long), c->stream));
+        p.timeline = c->dTimeline;
+    }
     if (stats) HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     const int rc = crt::launchRender(p, counting, c->stream);
     if (rc != 0) return fail(c, CRT_EHIP, "render kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
@@ -220,6 +237,7 @@ void crt_destroy(crt_ctx* c)
     for (int i = 0; i < 5; i++)
         if (c->dFrame[i]) (void)hipFree(c->dFrame[i]);
     if (c->dCounters) (void)hipFree(c->dCounters);
+    if (c->dTimeline) (void)hipFree(c->dTimeline);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
     if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
@@ -326,6 +344,14 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
         c->tuneInnerMin = static_cast<uint32_t>(value);
         return CRT_OK;
     }
+    if (std::strcmp(name, "xcd_group") == 0 && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) {
+        c->tuneXcdGroup = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "timeline") == 0) {
+        c->wantTimeline = value != 0;
+        return CRT_OK;
+    }
     if (std::strcmp(name, "block_size") == 0 && (value == 64 || value == 256)) {
         c->tuneBlockSize = static_cast<uint32_t>(value);
         return CRT_OK;
@@ -335,6 +361,16 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
         return CRT_OK;
     }
     return fail(c, CRT_EINVAL, "unknown option '%s' or value %d out of range", name, value);
+}
+
+int crt_debug_read_timeline(crt_ctx* c, unsigned long long* out, size_t max_words, size_t* n_words)
+{
+    if (!c || !out || !n_words) return CRT_EINVAL;
+    const size_t n = c->timelineWords < max_words ? c->timelineWords : max_words;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (n) HIP_TRY(c, hipMemcpy(out, c->dTimeline, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    *n_words = n;
+    return CRT_OK;
 }
 
 int crt_set_stream(crt_ctx* c, void* hip_stream)

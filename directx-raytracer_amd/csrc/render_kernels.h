@@ -32,6 +32,7 @@ struct RenderParams {
     uint32_t tune_inner_min;     // wave scheduling knob, see traceClosest()
     uint32_t stack_entries;      // per-lane LDS stack depth (>= BVH depth, <= kStackEntries)
     uint32_t block_size;         // 256 (4 wavefronts per workgroup) or 64 (one)
+    uint32_t xcd_group;          // consecutive tiles of the list handed to one XCD before moving to the next (1..16, power of 2)
     // outputs (device pointers, nullable except rgba8)
     uint32_t* rgba8;
     uint32_t* hit_inst;
@@ -39,6 +40,7 @@ struct RenderParams {
     float* hit_t;
     float* rgb_f32;
     unsigned long long* counters; // [0] nodes fetched, [1] triangles fetched, [2] shadow rays; used by the counting variant
+    unsigned long long* timeline; // counting variant only, nullable: per workgroup {start, end} of s_memrealtime (100 MHz) + XCC id
 };
 
 // Enqueue the fused rayGen -> traverse -> shade -> store kernel. counting selects the instrumented variant.

@@ -29,7 +29,7 @@ constexpr float kShadowBias = 1e-3f;
 constexpr float kFourPi = 12.566370614359172f;
 constexpr int kDone = INT_MIN;    // traversal finished (not a valid leaf reference)
 constexpr int kBlock = 256;
-constexpr uint32_t kGroup = 16; // tiles per XCD group (one 4x4-tile block when rendering on a single GPU)
+constexpr uint32_t kGroupMax = 16; // grid padding unit: tiles per XCD group never exceed this
 
 struct F3 { float x, y, z; };
 
@@ -377,6 +377,8 @@ template <bool COUNT, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void renderKernel(const RenderParams p)
 {
     extern __shared__ int s_stack[]; // stack_entries x 256 dwords, sized at launch from the BVH depth
+    unsigned long long t_start = 0;
+    if (p.timeline) t_start = __builtin_amdgcn_s_memrealtime();
 
     // XCD-aware remap. Workgroup b runs on XCD b % 8 (observed round-robin dispatch; speed only, never correctness).
     // The tile list is cut into groups of kGroup consecutive tiles and the groups are dealt round-robin to the XCDs:
@@ -387,6 +389,7 @@ __global__ __launch_bounds__(BLOCK) void renderKernel(const RenderParams p)
     const uint32_t b = blockIdx.x, xcd = b & 7u;
     const uint32_t seq = b >> 3; // position in this XCD's workgroup sequence
     const uint32_t i = BLOCK == 64 ? seq >> 2 : seq;
+    const uint32_t kGroup = p.xcd_group; // 1, 2, 4, 8 or 16 consecutive tiles of the list per XCD turn
     const uint32_t j = ((i / kGroup) * 8u + xcd) * kGroup + (i % kGroup); // position in this rank's tile list
     uint32_t tile_x, tile_y;
     if (p.n_ranks == 1) {
@@ -444,6 +447,14 @@ __global__ __launch_bounds__(BLOCK) void renderKernel(const RenderParams p)
             p.rgb_f32[3 * pix + 2] = col.z;
         }
     }
+    if (p.timeline && threadIdx.x == 0) {
+        // diagnostic build only: wave lifetime on the constant 100 MHz clock, and which XCD ran it
+        const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
+        const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu; // HW_REG_XCC_ID[3:0]
+        p.timeline[3 * static_cast<size_t>(blockIdx.x) + 0] = t_start;
+        p.timeline[3 * static_cast<size_t>(blockIdx.x) + 1] = t_end;
+        p.timeline[3 * static_cast<size_t>(blockIdx.x) + 2] = (static_cast<unsigned long long>(xcc) << 32) | (tile_y << 16) | tile_x;
+    }
     if (COUNT) {
         const uint32_t a = waveSum(cntNodes), c = waveSum(cntTris), s = waveSum(cntShadow);
         if (lane == 0) {
@@ -475,7 +486,7 @@ int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream)
     // list length: single GPU walks whole 4x4-tile blocks (padded at the frame edges); then padded to 8 XCDs x kGroup
     uint32_t n = p.n_local_tiles;
     if (p.n_ranks == 1) n = ((p.tiles_x + 3u) / 4u) * ((p.tiles_y + 3u) / 4u) * 16u;
-    n = (n + 8u * kGroup - 1u) / (8u * kGroup) * (8u * kGroup);
+    n = (n + 8u * kGroupMax - 1u) / (8u * kGroupMax) * (8u * kGroupMax);
     const uint32_t bs = p.block_size == 64 ? 64u : 256u;
     const dim3 grid(bs == 64 ? n * 4u : n), block(bs);
     const size_t lds = static_cast<size_t>(p.stack_entries) * bs * sizeof(int);

@@ -141,6 +141,10 @@ int crt_untile_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_
 /* tuning knobs (speed only, results never change). "inner_min" 1..65: wave scheduling of the traversal loop */
 int crt_set_option(crt_ctx* ctx, const char* name, int value);
 
+/* diagnostics: with option "timeline" = 1 and counting enabled, a render records per workgroup {start, end} on the
+ * 100 MHz s_memrealtime clock and (XCC id << 32 | tile_y << 16 | tile_x); this copies them out (3 words per workgroup) */
+int crt_debug_read_timeline(crt_ctx* ctx, unsigned long long* out, size_t max_words, size_t* n_words);
+
 /* stream plumbing: run on an external hipStream_t (e.g. torch's current stream; NULL = HIP's default stream);
  * crt_reset_stream goes back to the context's private non-blocking stream */
 int crt_set_stream(crt_ctx* ctx, void* hip_stream);
