@@ -41,6 +41,7 @@ struct crt_ctx {
     void* dMats = nullptr;
     uint32_t nLights = 0, nMats = 0;
     bool haveScene = false;
+    uint32_t sceneSerial = 0;
 
     float pos[3] = { 0.f, 0.f, 0.f };
     float rot[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f };
@@ -50,7 +51,12 @@ struct crt_ctx {
     uint32_t tuneInnerMin = 24;    // wave scheduling threshold of the traversal loop (render_kernels.hip)
     uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
     uint32_t tuneXcdGroup = 16;
-    uint32_t tuneBlockSize = 64;   // 64: one-wavefront workgroups (finer dispatch + LDS granularity, measured 5 % faster than 256)
+    uint32_t tuneBoostUnits = 512;
+    bool adaptiveOrder = true;     // launch the work units of frame N+1 in descending order of their cost in frame N
+    uint32_t* dUnitCost = nullptr;
+    uint32_t* dUnitOrder = nullptr;
+    uint32_t unitCapacity = 0;
+    uint64_t orderKey = 0;         // frame geometry the stored order belongs to; 0 = none
     unsigned long long* dCounters = nullptr;
     unsigned long long* dTimeline = nullptr; // diagnostic: 3 words per workgroup, counting variant only
     size_t timelineWords = 0;
@@ -132,9 +138,11 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.n_local_tiles = rank < nTiles ? (nTiles - rank + nRanks - 1) / nRanks : 0;
     p.counters = c->dCounters;
     p.timeline = nullptr;
+    p.unit_order = nullptr;
+    p.unit_cost = nullptr;
     p.tune_inner_min = c->tuneInnerMin;
-    p.block_size = c->tuneBlockSize;
     p.xcd_group = c->tuneXcdGroup;
+    p.boost_units = c->tuneBoostUnits;
     // a ray's stack never holds more entries than the tree is deep; fewer entries = less LDS = more resident waves
     uint32_t need = c->bvh.maxDepth < 4 ? 4 : c->bvh.maxDepth;
     need = (need + 1u) & ~1u;
@@ -157,9 +165,32 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         HIP_TRY(c, hipMemsetAsync(c->dTimeline, 0, c->timelineWords * sizeof(unsigned long long), c->stream));
         p.timeline = c->dTimeline;
     }
+    // cost feedback: this frame's per-unit critical paths order the next frame's launch (same frame geometry only)
+    const uint32_t nUnits = crt::renderUnitCount(p);
+    const uint64_t key = (static_cast<uint64_t>(p.width) << 40) ^ (static_cast<uint64_t>(p.height) << 20) ^
+                         (static_cast<uint64_t>(p.n_ranks) << 8) ^ p.rank ^ (static_cast<uint64_t>(c->sceneSerial) << 52) ^ 1ull;
+    if (c->adaptiveOrder && nUnits) {
+        if (c->unitCapacity < nUnits) {
+            if (c->dUnitCost) (void)hipFree(c->dUnitCost);
+            if (c->dUnitOrder) (void)hipFree(c->dUnitOrder);
+            c->dUnitCost = c->dUnitOrder = nullptr;
+            c->unitCapacity = 0;
+            c->orderKey = 0;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dUnitCost), sizeof(uint32_t) * nUnits));
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dUnitOrder), sizeof(uint32_t) * nUnits));
+            c->unitCapacity = nUnits;
+        }
+        p.unit_cost = c->dUnitCost;
+        p.unit_order = c->orderKey == key ? c->dUnitOrder : nullptr;
+    }
     if (stats) HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     const int rc = crt::launchRender(p, counting, c->stream);
     if (rc != 0) return fail(c, CRT_EHIP, "render kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+    if (p.unit_cost) {
+        const int rs = crt::launchSortUnits(c->dUnitCost, c->dUnitOrder, nUnits, c->stream);
+        if (rs != 0) return fail(c, CRT_EHIP, "sort kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rs)));
+        c->orderKey = key;
+    }
     if (stats) {
         HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
         HIP_TRY(c, hipEventSynchronize(c->evStop));
@@ -237,6 +268,8 @@ void crt_destroy(crt_ctx* c)
     for (int i = 0; i < 5; i++)
         if (c->dFrame[i]) (void)hipFree(c->dFrame[i]);
     if (c->dCounters) (void)hipFree(c->dCounters);
+    if (c->dUnitCost) (void)hipFree(c->dUnitCost);
+    if (c->dUnitOrder) (void)hipFree(c->dUnitOrder);
     if (c->dTimeline) (void)hipFree(c->dTimeline);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
@@ -303,6 +336,8 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     c->nLights = n_lights;
     c->nMats = n_materials;
     c->haveScene = true;
+    c->sceneSerial++;
+    c->orderKey = 0;
     return CRT_OK;
 }
 
@@ -348,12 +383,17 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
         c->tuneXcdGroup = static_cast<uint32_t>(value);
         return CRT_OK;
     }
+    if (std::strcmp(name, "boost_units") == 0 && value >= 0) {
+        c->tuneBoostUnits = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
     if (std::strcmp(name, "timeline") == 0) {
         c->wantTimeline = value != 0;
         return CRT_OK;
     }
-    if (std::strcmp(name, "block_size") == 0 && (value == 64 || value == 256)) {
-        c->tuneBlockSize = static_cast<uint32_t>(value);
+    if (std::strcmp(name, "adaptive_order") == 0) {
+        c->adaptiveOrder = value != 0;
+        c->orderKey = 0;
         return CRT_OK;
     }
     if (std::strcmp(name, "stack_entries") == 0 && (value == 0 || (value >= static_cast<int>(c->bvh.maxDepth) && value <= crt::kStackEntries))) {

@@ -31,7 +31,7 @@ struct RenderParams {
     uint32_t staging;            // 0: write row-major frame buffers; 1: rgba8 goes to the tile-major staging buffer
     uint32_t tune_inner_min;     // wave scheduling knob, see traceClosest()
     uint32_t stack_entries;      // per-lane LDS stack depth (>= BVH depth, <= kStackEntries)
-    uint32_t block_size;         // 256 (4 wavefronts per workgroup) or 64 (one)
+    uint32_t boost_units;        // with unit_order: the first boost_units (most expensive) work units run at raised priority
     uint32_t xcd_group;          // consecutive tiles of the list handed to one XCD before moving to the next (1..16, power of 2)
     // outputs (device pointers, nullable except rgba8)
     uint32_t* rgba8;
@@ -40,11 +40,17 @@ struct RenderParams {
     float* hit_t;
     float* rgb_f32;
     unsigned long long* counters; // [0] nodes fetched, [1] triangles fetched, [2] shadow rays; used by the counting variant
+    const uint32_t* unit_order;   // nullable: work units sorted by descending cost of the previous frame (launch order)
+    uint32_t* unit_cost;          // nullable: per work unit, traversal-loop iterations of its wavefront (this frame)
     unsigned long long* timeline; // counting variant only, nullable: per workgroup {start, end} of s_memrealtime (100 MHz) + XCC id
 };
 
 // Enqueue the fused rayGen -> traverse -> shade -> store kernel. counting selects the instrumented variant.
 int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream);
+// number of work units (= workgroups) launchRender uses for p: size of unit_order / unit_cost
+uint32_t renderUnitCount(const RenderParams& p);
+// unit_cost -> unit_order (descending)
+int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, ihipStream_t* stream);
 // tile-major gathered buffer -> row-major frame
 int launchUntile(const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height, uint32_t n_ranks,
                  uint32_t slots, ihipStream_t* stream);

@@ -29,6 +29,7 @@ constexpr float kShadowBias = 1e-3f;
 constexpr float kFourPi = 12.566370614359172f;
 constexpr int kDone = INT_MIN;    // traversal finished (not a valid leaf reference)
 constexpr int kBlock = 256;
+constexpr uint32_t kBoostAfter = 300; // traversal-loop iterations after which a wavefront raises its issue priority
 constexpr uint32_t kGroupMax = 16; // grid padding unit: tiles per XCD group never exceed this
 
 struct F3 { float x, y, z; };
@@ -170,7 +171,7 @@ __device__ __forceinline__ void nodeStep(const float4* __restrict__ nodes, const
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ void traceClosest(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                              uint32_t n_nodes, const Ray& r, float tmin, float tmax, int* stack, int innerMin,
-                                             Hit& h, uint32_t& cntNodes, uint32_t& cntTris)
+                                             Hit& h, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris)
 {
     h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
     int cur = n_nodes ? 0 : kDone;
@@ -180,6 +181,7 @@ __device__ __forceinline__ void traceClosest(const float4* __restrict__ nodes, c
         const unsigned long long innerMask = __ballot(cur >= 0);
         const unsigned long long leafMask = __ballot((cur < 0) & (cur != kDone));
         if ((innerMask | leafMask) == 0ull) break;
+        if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3); // a wavefront on a long critical path stops queueing behind the others
         if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
             if (cur >= 0) nodeStep<COUNT, BLOCK>(nodes, r, tmin, tcull, stack, cur, sp, cntNodes);
             continue;
@@ -213,7 +215,7 @@ __device__ __forceinline__ void traceClosest(const float4* __restrict__ nodes, c
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ bool traceAny(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                          uint32_t n_nodes, const Ray& r, float tmin, float tmax, int* stack, int innerMin,
-                                         uint32_t& cntNodes, uint32_t& cntTris)
+                                         uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris)
 {
     bool occluded = false;
     int cur = n_nodes ? 0 : kDone;
@@ -223,6 +225,7 @@ __device__ __forceinline__ bool traceAny(const float4* __restrict__ nodes, const
         const unsigned long long innerMask = __ballot(cur >= 0);
         const unsigned long long leafMask = __ballot((cur < 0) & (cur != kDone));
         if ((innerMask | leafMask) == 0ull) break;
+        if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3);
         if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
             if (cur >= 0) nodeStep<COUNT, BLOCK>(nodes, r, tmin, tcull, stack, cur, sp, cntNodes);
             continue;
@@ -318,7 +321,7 @@ struct MaterialRec { float r, g, b; uint32_t type; uint32_t smooth; float ior; }
 // Lambert + one shadow ray per light (mode 100): extension, specified by oracle/crt_oracle.c shade_lambert
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* nodes, const float4* tris, const Ray& r,
-                                           const Hit& h, int* stack, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
+                                           const Hit& h, int* stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
 {
     const float4* T = tris + 3 * static_cast<size_t>(h.tri);
     const float4 tb = T[1], tc = T[2];
@@ -355,7 +358,7 @@ __device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* 
         if (cosv > 0.0f) {
             const Ray sr = makeRay(Po, Ld);
             if (COUNT) cntShadow++;
-            const bool occluded = traceAny<COUNT, BLOCK>(nodes, tris, p.n_nodes, sr, 0.0f, dist, stack, static_cast<int>(p.tune_inner_min), cntNodes, cntTris);
+            const bool occluded = traceAny<COUNT, BLOCK>(nodes, tris, p.n_nodes, sr, 0.0f, dist, stack, static_cast<int>(p.tune_inner_min), iters, cntNodes, cntTris);
             if (!occluded) {
                 const float k = (L.intensity / (kFourPi * r2)) * cosv;
                 rgb.x = fmaf(albedo.x, k, rgb.x);
@@ -378,41 +381,57 @@ __global__ __launch_bounds__(BLOCK) void renderKernel(const RenderParams p)
 {
     extern __shared__ int s_stack[]; // stack_entries x 256 dwords, sized at launch from the BVH depth
     unsigned long long t_start = 0;
-    if (p.timeline) t_start = __builtin_amdgcn_s_memrealtime();
+    if (p.timeline || p.unit_cost) t_start = __builtin_amdgcn_s_memrealtime();
 
-    // XCD-aware remap. Workgroup b runs on XCD b % 8 (observed round-robin dispatch; speed only, never correctness).
-    // The tile list is cut into groups of kGroup consecutive tiles and the groups are dealt round-robin to the XCDs:
-    // an XCD's consecutive workgroups stay inside one group (its L2 keeps that group's subtrees) while all XCDs sweep
-    // the frame together (sky rows cost nothing, so a contiguous band per XCD would leave most of the chip idle).
-    // BLOCK = 256: one workgroup per 16x16 macro tile (4 wavefronts). BLOCK = 64: one single-wavefront workgroup per
-    // 8x8 sub-tile, the 4 sub-tiles of a macro tile consecutive on the same XCD (finer dispatch and LDS granularity).
-    const uint32_t b = blockIdx.x, xcd = b & 7u;
-    const uint32_t seq = b >> 3; // position in this XCD's workgroup sequence
-    const uint32_t i = BLOCK == 64 ? seq >> 2 : seq;
-    const uint32_t kGroup = p.xcd_group; // 1, 2, 4, 8 or 16 consecutive tiles of the list per XCD turn
-    const uint32_t j = ((i / kGroup) * 8u + xcd) * kGroup + (i % kGroup); // position in this rank's tile list
+    // Work unit = one 8x8-pixel packet = one single-wavefront workgroup; unit u = 4 * j + sub, j = position of the 16x16
+    // macro tile in this rank's tile list, sub = which 8x8 quarter.  Which unit a workgroup takes:
+    //  * with a cost-sorted order from the previous frame (p.unit_order): the blockIdx-th most expensive unit, so the
+    //    packets on the longest critical paths start first and the kernel's tail disappears (longest-processing-time
+    //    first; the dispatcher hands out workgroups in blockIdx order);
+    //  * otherwise: workgroup b runs on XCD b % 8 (observed round-robin dispatch); groups of xcd_group consecutive tiles
+    //    of the list are dealt round-robin to the XCDs so all XCDs sweep the frame together.
+    // Either way this is scheduling only: results never depend on it.
+    const uint32_t b = blockIdx.x;
+    uint32_t unit;
+    if (p.unit_order) {
+        unit = p.unit_order[b];
+        // the few packets with the longest critical paths bound the frame time even when they start first: let them
+        // issue ahead of the other resident wavefronts
+        if (b < p.boost_units) __builtin_amdgcn_s_setprio(3);
+    } else {
+        const uint32_t xcd = b & 7u, seq = b >> 3, i = seq >> 2;
+        const uint32_t kGroup = p.xcd_group;
+        unit = ((((i / kGroup) * 8u + xcd) * kGroup + (i % kGroup)) << 2) | (seq & 3u);
+    }
+    const uint32_t j = unit >> 2;
     uint32_t tile_x, tile_y;
+    bool valid;
     if (p.n_ranks == 1) {
         // single GPU: the list walks 4x4-tile (64x64-pixel) blocks row-major, tiles row-major inside a block
         const uint32_t blocks_x = (p.tiles_x + 3u) >> 2;
         const uint32_t blk = j >> 4, within = j & 15u;
         tile_x = (blk % blocks_x) * 4u + (within & 3u);
         tile_y = (blk / blocks_x) * 4u + (within >> 2);
-        if (tile_x >= p.tiles_x || tile_y >= p.tiles_y) return;
+        valid = (tile_x < p.tiles_x) & (tile_y < p.tiles_y);
     } else {
         // N GPUs: macro tile k (row-major) belongs to rank k % N; this rank's list is k = j*N + rank
         const uint32_t k = j * p.n_ranks + p.rank;
-        if (k >= p.tiles_x * p.tiles_y) return;
+        valid = k < p.tiles_x * p.tiles_y;
         tile_x = k % p.tiles_x;
         tile_y = k / p.tiles_x;
     }
+    if (!valid) {
+        if (p.unit_cost && threadIdx.x == 0) p.unit_cost[unit] = 0;
+        return;
+    }
 
-    const uint32_t tid = threadIdx.x, wave = BLOCK == 64 ? (seq & 3u) : (tid >> 6), lane = tid & 63u;
+    const uint32_t tid = threadIdx.x, wave = unit & 3u, lane = tid & 63u;
     const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
     const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
     const bool active = (px < p.width) & (py < p.height);
 
     uint32_t cntNodes = 0, cntTris = 0, cntShadow = 0;
+    uint32_t iters = 0; // traversal-loop iterations of this wavefront = its critical path, fed back as next frame's cost
     if (active) {
         const float4* nodes = reinterpret_cast<const float4*>(p.nodes);
         const float4* tris = reinterpret_cast<const float4*>(p.tris);
@@ -421,7 +440,7 @@ __global__ __launch_bounds__(BLOCK) void renderKernel(const RenderParams p)
         const F3 o = f3(p.pos[0], p.pos[1], p.pos[2]);
         const Ray r = makeRay(o, rayDir(p.rot, px, py, static_cast<float>(p.width), static_cast<float>(p.height)));
         Hit h;
-        traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, cntNodes, cntTris);
+        traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, iters, cntNodes, cntTris);
 
         F3 col = f3(p.miss[0], p.miss[1], p.miss[2]); // miss shader (hlsl:72-76)
         uint32_t inst = 0xFFFFFFFFu, prim = 0xFFFFFFFFu;
@@ -430,7 +449,7 @@ __global__ __launch_bounds__(BLOCK) void renderKernel(const RenderParams p)
             const float4* T = tris + 3 * static_cast<size_t>(h.tri);
             inst = __float_as_uint(T[0].w);
             prim = __float_as_uint(T[1].w);
-            if (p.mode >= 100u) col = shadeLambert<COUNT, BLOCK>(p, nodes, tris, r, h, stack, cntNodes, cntTris, cntShadow);
+            if (p.mode >= 100u) col = shadeLambert<COUNT, BLOCK>(p, nodes, tris, r, h, stack, iters, cntNodes, cntTris, cntShadow);
             else col = shadeDebug(p.mode, inst, prim, h.t, h.u, h.v, r.o, r.d);
         }
 
@@ -447,6 +466,9 @@ __global__ __launch_bounds__(BLOCK) void renderKernel(const RenderParams p)
             p.rgb_f32[3 * pix + 2] = col.z;
         }
     }
+    // cost fed back to order the next frame = this wavefront's lifetime in 0.64 us units (constant 100 MHz clock): it
+    // sees what an iteration count does not (distant, incoherent packets are slow per iteration: cache misses)
+    if (p.unit_cost && threadIdx.x == 0) p.unit_cost[unit] = static_cast<uint32_t>((__builtin_amdgcn_s_memrealtime() - t_start) >> 6);
     if (p.timeline && threadIdx.x == 0) {
         // diagnostic build only: wave lifetime on the constant 100 MHz clock, and which XCD ran it
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
@@ -480,23 +502,56 @@ __global__ __launch_bounds__(kBlock) void untileKernel(const uint32_t* __restric
 
 } // namespace
 
-int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream)
+uint32_t renderUnitCount(const RenderParams& p)
 {
-    if (p.n_local_tiles == 0) return 0;
-    // list length: single GPU walks whole 4x4-tile blocks (padded at the frame edges); then padded to 8 XCDs x kGroup
     uint32_t n = p.n_local_tiles;
     if (p.n_ranks == 1) n = ((p.tiles_x + 3u) / 4u) * ((p.tiles_y + 3u) / 4u) * 16u;
     n = (n + 8u * kGroupMax - 1u) / (8u * kGroupMax) * (8u * kGroupMax);
-    const uint32_t bs = p.block_size == 64 ? 64u : 256u;
-    const dim3 grid(bs == 64 ? n * 4u : n), block(bs);
-    const size_t lds = static_cast<size_t>(p.stack_entries) * bs * sizeof(int);
-    if (bs == 64) {
-        if (counting) hipLaunchKernelGGL((renderKernel<true, 64>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((renderKernel<false, 64>), grid, block, lds, stream, p);
-    } else {
-        if (counting) hipLaunchKernelGGL((renderKernel<true, 256>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((renderKernel<false, 256>), grid, block, lds, stream, p);
+    return n * 4u;
+}
+
+int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream)
+{
+    if (p.n_local_tiles == 0) return 0;
+    // list length: single GPU walks whole 4x4-tile blocks (padded at the frame edges); then padded to 8 XCDs x kGroupMax
+    const uint32_t n = renderUnitCount(p) / 4u;
+    const dim3 grid(n * 4u), block(64);
+    const size_t lds = static_cast<size_t>(p.stack_entries) * 64u * sizeof(int);
+    if (counting) hipLaunchKernelGGL((renderKernel<true, 64>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((renderKernel<false, 64>), grid, block, lds, stream, p);
+    return static_cast<int>(hipGetLastError());
+}
+
+// Order the work units by descending cost (counting sort on min(cost, 1023); order inside a bucket is arbitrary).
+__global__ __launch_bounds__(1024) void sortUnitsKernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n)
+{
+    __shared__ uint32_t hist[1024];
+    __shared__ uint32_t offs[1024];
+    const uint32_t t = threadIdx.x;
+    hist[t] = 0;
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024u) atomicAdd(&hist[min(cost[i], 1023u)], 1u);
+    __syncthreads();
+    // bucket 1023 first: offs[b] = number of units in buckets above b (inclusive scan over the reversed histogram)
+    uint32_t v = hist[1023u - t];
+    offs[t] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024u; d <<= 1) {
+        const uint32_t add = t >= d ? offs[t - d] : 0u;
+        __syncthreads();
+        offs[t] += add;
+        __syncthreads();
     }
+    const uint32_t excl = offs[t] - v; // exclusive prefix of reversed bucket t
+    __syncthreads();
+    hist[1023u - t] = excl;            // hist[b] now = first output slot of bucket b
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 1024u) order[atomicAdd(&hist[min(cost[i], 1023u)], 1u)] = i;
+}
+
+int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, ihipStream_t* stream)
+{
+    hipLaunchKernelGGL(sortUnitsKernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
     return static_cast<int>(hipGetLastError());
 }
 

@@ -27,7 +27,7 @@ frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
 res = {v: [] for v in a.values}
 for rnd in range(a.rounds + 1):
     for v in a.values:
-        r.set_option(a.option, v)
+        r.set_option(a.option, v); r.render_frame_device(W, H, frame.data_ptr(), stats=True)
         ms = [r.render_frame_device(W, H, frame.data_ptr(), stats=True)["kernel_ms"] for _ in range(a.frames)]
         if rnd:
             res[v].append(statistics.median(ms))

@@ -32,3 +32,11 @@ for a, b in zip(edges[:-1], edges[1:]):
     res = ((s <= mid) & (en > mid)).sum()
     print("t=%7.1f us resident waves %5d  started in bin %5d" % (mid, res, ((s >= a) & (s < b)).sum()))
 print("per-XCC waves:", np.bincount(xcc, minlength=8), " per-XCC last end (us):", [round(float(en[xcc == x].max()), 1) if (xcc == x).any() else None for x in range(8)])
+idx = np.nonzero(r.read_timeline()[:, 1] > 0)[0]
+last = np.argsort(en)[-12:]
+print("latest-ending waves: (blockIdx, start_us, life_us, xcc, tile)")
+for k in last:
+    print("   b=%6d start %7.1f life %7.1f xcc %d tile (%d,%d)" % (idx[k], s[k], life[k], xcc[k], int(tl[k, 2]) & 0xFFFF, (int(tl[k, 2]) >> 16) & 0xFFFF))
+firsts = np.argsort(idx)[:6400]
+print("first 6400 blockIdx: start time max %.1f us; lifetimes mean %.1f max %.1f" % (s[firsts].max(), life[firsts].mean(), life[firsts].max()))
+print("start time vs blockIdx correlation:", np.corrcoef(idx, s)[0, 1])
