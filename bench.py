@@ -191,7 +191,9 @@ def main():
         if world == 1:
             # dominant (only) kernel: renderKernel<false>; algorithmic bytes of one launch / average launch duration
             # over the timed region (HIP events on its stream)
-            achieved = alg_bytes_frame / (stream_ms / args.steps * 1e-3) / 1e9
+            # duration of that kernel alone: median of per-launch HIP events recorded around it on its stream (the timed
+            # region also holds the 1-workgroup sortUnitsKernel that orders the next frame's launch, ~2 % of a step)
+            achieved = alg_bytes_frame / (kernel_ms * 1e-3) / 1e9
             traffic = None
             tfile = os.path.join(ROOT, "profiles", "hbm_traffic.json")
             if os.path.exists(tfile):
@@ -201,7 +203,7 @@ def main():
                     traffic = None
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                                "kernel": "renderKernel<false>", "algorithmic_bytes_per_launch": alg_bytes_frame,
+                                "kernel": "renderKernel<false, 64>", "algorithmic_bytes_per_launch": alg_bytes_frame,
                                 "nodes_fetched": cnt["nodes_visited"], "tris_fetched": cnt["tris_tested"],
                                 "kernel_ms_event_median": kernel_ms,
                                 "note": "bytes = 64 B x node records fetched + 48 B x triangle records fetched + 4 B x pixels; "

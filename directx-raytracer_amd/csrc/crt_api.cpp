@@ -48,7 +48,7 @@ struct crt_ctx {
     float miss[3] = { 0.f, 1.f, 1.f }; // hlsl:75
     uint32_t mode = 0;                 // R/DXRTRenderer.h:246 default shading mode
     bool counting = false;
-    uint32_t tuneInnerMin = 24;    // wave scheduling threshold of the traversal loop (render_kernels.hip)
+    uint32_t tuneInnerMin = 16;    // wave scheduling threshold of the traversal loop (render_kernels.hip)
     uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
     uint32_t tuneXcdGroup = 16;
     uint32_t tuneBoostUnits = 512;
@@ -186,14 +186,14 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
     if (stats) HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     const int rc = crt::launchRender(p, counting, c->stream);
     if (rc != 0) return fail(c, CRT_EHIP, "render kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
+    if (stats) HIP_TRY(c, hipEventRecord(c->evStop, c->stream)); // kernel_ms = the render kernel alone
     if (p.unit_cost) {
         const int rs = crt::launchSortUnits(c->dUnitCost, c->dUnitOrder, nUnits, c->stream);
         if (rs != 0) return fail(c, CRT_EHIP, "sort kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rs)));
         c->orderKey = key;
     }
     if (stats) {
-        HIP_TRY(c, hipEventRecord(c->evStop, c->stream));
-        HIP_TRY(c, hipEventSynchronize(c->evStop));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
         float ms = 0.f;
         HIP_TRY(c, hipEventElapsedTime(&ms, c->evStart, c->evStop));
         std::memset(stats, 0, sizeof(*stats));

@@ -195,3 +195,38 @@ def test_external_stream_and_error_paths(pkg, scenes, renderer):
     r2.close()
     with pytest.raises(pkg.CrtError):
         pkg.Renderer(99)
+
+
+def test_scheduling_knobs_never_change_results(pkg, oracle, scenes, dragon, renderer):
+    """Wave scheduling (inner_min), XCD grouping, cost-feedback launch order, priority boost and LDS stack size are
+    speed knobs only: every setting must give the oracle's frame bit for bit (and the same fetch counters)."""
+    sc = _with_normals(scenes, dragon)
+    cam = sc["camera"]
+    renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+    renderer.set_camera(cam["position"], cam["matrix"])
+    renderer.change_shading_mode(100)
+    w, h = 640, 360
+    ref = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"]).render(cam["position"], cam["matrix"], 100, w, h)
+    defaults = {"inner_min": 16, "xcd_group": 16, "adaptive_order": 1, "boost_units": 512, "stack_entries": 0}
+    try:
+        for name, values in (("inner_min", (1, 7, 33, 65)), ("xcd_group", (1, 4)), ("adaptive_order", (0, 1)),
+                             ("boost_units", (0, 100000)), ("stack_entries", (20, 32))):
+            for v in values:
+                renderer.set_option(name, v)
+                renderer.set_counting(True)
+                for frame in range(3):  # frames 2 and 3 run in the cost-sorted order of the previous one
+                    got = renderer.render_frame(w, h)
+                    for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
+                        np.testing.assert_array_equal(got[k], ref[k], err_msg="%s=%d frame %d %s" % (name, v, frame, k))
+                    assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True)
+                    assert got["stats"]["nodes_visited"] == ref["stats"]["nodes_visited"]
+                    assert got["stats"]["tris_tested"] == ref["stats"]["tris_tested"]
+            renderer.set_option(name, defaults[name])
+        with pytest.raises(pkg.CrtError):
+            renderer.set_option("no_such_option", 1)
+        with pytest.raises(pkg.CrtError):
+            renderer.set_option("stack_entries", 3)  # below the BVH depth: refused, would overflow the LDS stack
+    finally:
+        renderer.set_counting(False)
+        for name, v in defaults.items():
+            renderer.set_option(name, v)

@@ -17,7 +17,7 @@ import csv, glob, collections, statistics, json
 acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/pass*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "renderKernel<false>" in r["Kernel_Name"]:
+        if "renderKernel<false" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 res = {k: statistics.median(v) for k, v in sorted(acc.items())}
 json.dump(res, open("$OUT/summary.json", "w"), indent=1)
