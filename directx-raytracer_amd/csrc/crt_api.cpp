@@ -53,10 +53,14 @@ struct crt_ctx {
     uint32_t tuneXcdGroup = 16;
     uint32_t tuneBoostUnits = 512;
     bool adaptiveOrder = true;     // launch the work units of frame N+1 in descending order of their cost in frame N
-    uint32_t* dUnitCost = nullptr;
-    uint32_t* dUnitOrder = nullptr;
+    uint32_t* dUnitCost[2] = { nullptr, nullptr };
+    uint32_t* dUnitOrder[2] = { nullptr, nullptr };
     uint32_t unitCapacity = 0;
-    uint64_t orderKey = 0;         // frame geometry the stored order belongs to; 0 = none
+    uint64_t orderKey[2] = { 0, 0 }; // frame geometry each stored order belongs to; 0 = none
+    bool sortPending[2] = { false, false };
+    uint32_t frameSerial = 0;
+    hipStream_t sideStream = nullptr; // runs the sort of frame k concurrently with the render of frame k+1
+    hipEvent_t evRender[2] = { nullptr, nullptr }, evSort[2] = { nullptr, nullptr };
     unsigned long long* dCounters = nullptr;
     unsigned long long* dTimeline = nullptr; // diagnostic: 3 words per workgroup, counting variant only
     size_t timelineWords = 0;
@@ -165,32 +169,51 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         HIP_TRY(c, hipMemsetAsync(c->dTimeline, 0, c->timelineWords * sizeof(unsigned long long), c->stream));
         p.timeline = c->dTimeline;
     }
-    // cost feedback: this frame's per-unit critical paths order the next frame's launch (same frame geometry only)
+    // Cost feedback: the lifetimes frame k's wavefronts report are sorted on a side stream WHILE frame k+1 renders and
+    // order the launch of frame k+2 (two alternating buffer sets), so the sort never sits on the frame's critical path.
+    // Hint only: a stale or missing order changes speed, never results.
     const uint32_t nUnits = crt::renderUnitCount(p);
     const uint64_t key = (static_cast<uint64_t>(p.width) << 40) ^ (static_cast<uint64_t>(p.height) << 20) ^
                          (static_cast<uint64_t>(p.n_ranks) << 8) ^ p.rank ^ (static_cast<uint64_t>(c->sceneSerial) << 52) ^ 1ull;
+    const uint32_t slot = c->frameSerial & 1u;
+    bool feedback = false;
     if (c->adaptiveOrder && nUnits) {
         if (c->unitCapacity < nUnits) {
-            if (c->dUnitCost) (void)hipFree(c->dUnitCost);
-            if (c->dUnitOrder) (void)hipFree(c->dUnitOrder);
-            c->dUnitCost = c->dUnitOrder = nullptr;
+            HIP_TRY(c, hipStreamSynchronize(c->sideStream));
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            for (int i = 0; i < 2; i++) {
+                if (c->dUnitCost[i]) (void)hipFree(c->dUnitCost[i]);
+                if (c->dUnitOrder[i]) (void)hipFree(c->dUnitOrder[i]);
+                c->dUnitCost[i] = c->dUnitOrder[i] = nullptr;
+                c->orderKey[i] = 0;
+                c->sortPending[i] = false;
+            }
             c->unitCapacity = 0;
-            c->orderKey = 0;
-            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dUnitCost), sizeof(uint32_t) * nUnits));
-            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dUnitOrder), sizeof(uint32_t) * nUnits));
+            for (int i = 0; i < 2; i++) {
+                HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dUnitCost[i]), sizeof(uint32_t) * nUnits));
+                HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dUnitOrder[i]), sizeof(uint32_t) * nUnits));
+            }
             c->unitCapacity = nUnits;
         }
-        p.unit_cost = c->dUnitCost;
-        p.unit_order = c->orderKey == key ? c->dUnitOrder : nullptr;
+        // the sort of frame k-2 read cost[slot] and wrote order[slot]: it must be done before this frame touches either
+        if (c->sortPending[slot]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evSort[slot], 0));
+        p.unit_cost = c->dUnitCost[slot];
+        p.unit_order = c->orderKey[slot] == key ? c->dUnitOrder[slot] : nullptr;
+        feedback = true;
     }
     if (stats) HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     const int rc = crt::launchRender(p, counting, c->stream);
     if (rc != 0) return fail(c, CRT_EHIP, "render kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
     if (stats) HIP_TRY(c, hipEventRecord(c->evStop, c->stream)); // kernel_ms = the render kernel alone
-    if (p.unit_cost) {
-        const int rs = crt::launchSortUnits(c->dUnitCost, c->dUnitOrder, nUnits, c->stream);
+    if (feedback) {
+        HIP_TRY(c, hipEventRecord(c->evRender[slot], c->stream));
+        HIP_TRY(c, hipStreamWaitEvent(c->sideStream, c->evRender[slot], 0));
+        const int rs = crt::launchSortUnits(c->dUnitCost[slot], c->dUnitOrder[slot], nUnits, c->sideStream);
         if (rs != 0) return fail(c, CRT_EHIP, "sort kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rs)));
-        c->orderKey = key;
+        HIP_TRY(c, hipEventRecord(c->evSort[slot], c->sideStream));
+        c->sortPending[slot] = true;
+        c->orderKey[slot] = key;
+        c->frameSerial++;
     }
     if (stats) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -249,6 +272,9 @@ int crt_create(crt_ctx** out, int device_id)
     c->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->evRender[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evRender[1], hipEventDisableTiming)) != hipSuccess ||
+        (e = hipEventCreateWithFlags(&c->evSort[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evSort[1], hipEventDisableTiming)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->dCounters), 3 * sizeof(unsigned long long))) != hipSuccess) {
         const int rc = fail(nullptr, CRT_ENODEVICE, "HIP initialisation failed on device %d: %s", device_id, hipGetErrorString(e));
         crt_destroy(c);
@@ -268,8 +294,14 @@ void crt_destroy(crt_ctx* c)
     for (int i = 0; i < 5; i++)
         if (c->dFrame[i]) (void)hipFree(c->dFrame[i]);
     if (c->dCounters) (void)hipFree(c->dCounters);
-    if (c->dUnitCost) (void)hipFree(c->dUnitCost);
-    if (c->dUnitOrder) (void)hipFree(c->dUnitOrder);
+    if (c->sideStream) (void)hipStreamSynchronize(c->sideStream);
+    for (int i = 0; i < 2; i++) {
+        if (c->dUnitCost[i]) (void)hipFree(c->dUnitCost[i]);
+        if (c->dUnitOrder[i]) (void)hipFree(c->dUnitOrder[i]);
+        if (c->evRender[i]) (void)hipEventDestroy(c->evRender[i]);
+        if (c->evSort[i]) (void)hipEventDestroy(c->evSort[i]);
+    }
+    if (c->sideStream) (void)hipStreamDestroy(c->sideStream);
     if (c->dTimeline) (void)hipFree(c->dTimeline);
     if (c->evStart) (void)hipEventDestroy(c->evStart);
     if (c->evStop) (void)hipEventDestroy(c->evStop);
@@ -337,7 +369,7 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     c->nMats = n_materials;
     c->haveScene = true;
     c->sceneSerial++;
-    c->orderKey = 0;
+    c->orderKey[0] = c->orderKey[1] = 0;
     return CRT_OK;
 }
 
@@ -393,7 +425,7 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
     }
     if (std::strcmp(name, "adaptive_order") == 0) {
         c->adaptiveOrder = value != 0;
-        c->orderKey = 0;
+        c->orderKey[0] = c->orderKey[1] = 0;
         return CRT_OK;
     }
     if (std::strcmp(name, "stack_entries") == 0 && (value == 0 || (value >= static_cast<int>(c->bvh.maxDepth) && value <= crt::kStackEntries))) {
