@@ -71,6 +71,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--scene", default="heightfield", choices=["heightfield", "soup"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="rehearse the N>1 code path (RCCL init, tile staging, all-gather, "
+                    "de-interleave) with whatever world size the launcher gives, even 1")
     args = ap.parse_args()
 
     import torch
@@ -86,8 +88,13 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
 
     pkg = entry.load_package()
@@ -114,7 +121,7 @@ def main():
     rays_per_frame = cnt["rays_primary"] + cnt["rays_shadow"]
     alg_bytes_frame = 64 * cnt["nodes_visited"] + 48 * cnt["tris_tested"] + 4 * W * H
 
-    if world == 1:
+    if not multi:
         def step():
             r.render_frame_device(W, H, frame.data_ptr())
     else:
@@ -131,7 +138,7 @@ def main():
             host.gather_frame(staging, W, H, untile, gathered)
 
     def fence():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -147,7 +154,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     stream_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on
-    if world > 1:
+    if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -155,7 +162,7 @@ def main():
     # own-kernel share of this rank, measured per launch with the library's HIP events (render kernel only)
     kms = []
     for _ in range(min(20, args.steps)):
-        if world == 1:
+        if not multi:
             kms.append(r.render_frame_device(W, H, frame.data_ptr(), stats=True)["kernel_ms"])
         else:
             kms.append(r.render_tiles_device(W, H, rank, world, staging.data_ptr(), stats=True)["kernel_ms"])
@@ -163,7 +170,7 @@ def main():
 
     # PCIe-inclusive variant (host output buffer handed over the C ABI), for DESIGN.md; never `value`
     d2h_ms = None
-    if world == 1:
+    if not multi:
         r.reset_stream()
         r.render_frame(W, H, want=())
         t0 = time.perf_counter()
@@ -188,7 +195,7 @@ def main():
             "ms_per_frame": ms_per_step,
             "stream_ms_per_step": stream_ms / args.steps,
         }
-        if world == 1:
+        if not multi:
             # dominant (only) kernel: renderKernel<false>; algorithmic bytes of one launch / average launch duration
             # over the timed region (HIP events on its stream)
             # duration of that kernel alone: median of per-launch HIP events recorded around it on its stream (the timed
@@ -215,7 +222,7 @@ def main():
         else:
             line["rank0_render_kernel_ms"] = kernel_ms
         print(json.dumps(line))
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     r.close()

@@ -17,6 +17,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libcrt_hip.so")
 MISS = 0xFFFFFFFF
 MODE_LAMBERT = 100
+MODE_PATH = 200
 TILE = 16
 
 NODE_DTYPE = np.dtype([("lx0", "f4"), ("lx1", "f4"), ("ly0", "f4"), ("ly1", "f4"),
@@ -446,6 +447,12 @@ class Renderer:
 
     def set_counting(self, on):
         self._ok(lib().crt_set_counting(self.h, int(bool(on))), "crt_set_counting")
+
+    def set_path_params(self, spp=4, max_bounces=3, seed=1234):
+        """mode 200 (path tracing) parameters"""
+        self.set_option("spp", spp)
+        self.set_option("max_bounces", max_bounces)
+        self.set_option("seed", seed)
 
     def set_option(self, name, value):
         self._ok(lib().crt_set_option(self.h, name.encode(), int(value)), "crt_set_option")

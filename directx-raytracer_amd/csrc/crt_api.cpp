@@ -48,6 +48,7 @@ struct crt_ctx {
     float miss[3] = { 0.f, 1.f, 1.f }; // hlsl:75
     uint32_t mode = 0;                 // R/DXRTRenderer.h:246 default shading mode
     bool counting = false;
+    uint32_t pathSpp = 4, pathBounces = 3, pathSeed = 1234; // mode 200 (BASELINE.json configs[4]: 4 spp, 3 bounces)
     uint32_t tuneInnerMin = 16;    // wave scheduling threshold of the traversal loop (render_kernels.hip)
     uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
     uint32_t tuneXcdGroup = 16;
@@ -132,6 +133,9 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     std::memcpy(p.rot, c->rot, sizeof(p.rot));
     std::memcpy(p.miss, c->miss, sizeof(p.miss));
     p.mode = c->mode;
+    p.spp = c->pathSpp;
+    p.max_bounces = c->pathBounces;
+    p.seed = c->pathSeed;
     p.width = w;
     p.height = h;
     p.tiles_x = (w + crt::kTile - 1) / crt::kTile;
@@ -157,7 +161,7 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
 int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
 {
     const bool counting = c->counting;
-    if (counting) HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 3 * sizeof(unsigned long long), c->stream));
+    if (counting) HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 4 * sizeof(unsigned long long), c->stream));
     if (c->wantTimeline) {
         const size_t words = 3 * (static_cast<size_t>(p.tiles_x + 4) * (p.tiles_y + 4) * 4 + 1024);
         if (c->timelineWords < words) {
@@ -233,11 +237,12 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         }
         stats->rays_primary = pix;
         if (counting) {
-            unsigned long long host[3] = { 0, 0, 0 };
+            unsigned long long host[4] = { 0, 0, 0, 0 };
             HIP_TRY(c, hipMemcpy(host, c->dCounters, sizeof(host), hipMemcpyDeviceToHost));
             stats->nodes_visited = host[0];
             stats->tris_tested = host[1];
             stats->rays_shadow = host[2];
+            stats->rays_primary = host[3]; // closest-hit rays: camera rays, plus bounce rays in mode 200
         }
     }
     return CRT_OK;
@@ -275,7 +280,7 @@ int crt_create(crt_ctx** out, int device_id)
         (e = hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->evRender[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evRender[1], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->evSort[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evSort[1], hipEventDisableTiming)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&c->dCounters), 3 * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc(reinterpret_cast<void**>(&c->dCounters), 4 * sizeof(unsigned long long))) != hipSuccess) {
         const int rc = fail(nullptr, CRT_ENODEVICE, "HIP initialisation failed on device %d: %s", device_id, hipGetErrorString(e));
         crt_destroy(c);
         return rc;
@@ -407,6 +412,18 @@ int crt_set_counting(crt_ctx* c, int enabled)
 int crt_set_option(crt_ctx* c, const char* name, int value)
 {
     if (!c || !name) return CRT_EINVAL;
+    if (std::strcmp(name, "spp") == 0 && value >= 1 && value <= 65536) {
+        c->pathSpp = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "max_bounces") == 0 && value >= 0 && value <= 64) {
+        c->pathBounces = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "seed") == 0) {
+        c->pathSeed = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
     if (std::strcmp(name, "inner_min") == 0 && value >= 1 && value <= 65) {
         c->tuneInnerMin = static_cast<uint32_t>(value);
         return CRT_OK;

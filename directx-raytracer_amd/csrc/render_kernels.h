@@ -23,6 +23,7 @@ struct RenderParams {
     float rot[9];
     float miss[3];
     uint32_t mode;
+    uint32_t spp, max_bounces, seed; // mode 200 (path tracing)
     uint32_t width, height;
     // tiling
     uint32_t tiles_x, tiles_y;   // ceil(width/16), ceil(height/16)
@@ -39,7 +40,7 @@ struct RenderParams {
     uint32_t* hit_prim;
     float* hit_t;
     float* rgb_f32;
-    unsigned long long* counters; // [0] nodes fetched, [1] triangles fetched, [2] shadow rays; used by the counting variant
+    unsigned long long* counters; // [0] nodes fetched, [1] triangles fetched, [2] shadow rays, [3] closest-hit rays; counting variant
     const uint32_t* unit_order;   // nullable: work units sorted by descending cost of the previous frame (launch order)
     uint32_t* unit_cost;          // nullable: per work unit, traversal-loop iterations of its wavefront (this frame)
     unsigned long long* timeline; // counting variant only, nullable: per workgroup {start, end} of s_memrealtime (100 MHz) + XCC id

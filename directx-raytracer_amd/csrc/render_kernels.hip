@@ -255,11 +255,11 @@ __device__ __forceinline__ bool traceAny(const float4* __restrict__ nodes, const
 }
 
 // rayGen (hlsl:21-55) with width/height as parameters instead of the literals 1920/1080 (hlsl:24-25)
-__device__ __forceinline__ F3 rayDir(const float* rot, uint32_t px, uint32_t py, float width, float height)
+__device__ __forceinline__ F3 rayDirJ(const float* rot, uint32_t px, uint32_t py, float jx, float jy, float width, float height)
 {
     float x = static_cast<float>(px), y = static_cast<float>(py);
-    x += 0.5f;
-    y += 0.5f;
+    x += jx; // 0.5 in the reference (hlsl:35-36); the path tracer jitters inside the pixel
+    y += jy;
     x /= width;
     y /= height;
     x = (2.0f * x) - 1.0f;
@@ -269,6 +269,11 @@ __device__ __forceinline__ F3 rayDir(const float* rot, uint32_t px, uint32_t py,
     const F3 dw = f3(dot3(f3(rot[0], rot[1], rot[2]), dc), dot3(f3(rot[3], rot[4], rot[5]), dc),
                      dot3(f3(rot[6], rot[7], rot[8]), dc));
     return normalize3(dw);
+}
+
+__device__ __forceinline__ F3 rayDir(const float* rot, uint32_t px, uint32_t py, float width, float height)
+{
+    return rayDirJ(rot, px, py, 0.5f, 0.5f, width, height);
 }
 
 __device__ __forceinline__ F3 objectBaseColour(uint32_t inst) // hlsl:97-101,117-121
@@ -318,22 +323,32 @@ __device__ __forceinline__ F3 shadeDebug(uint32_t mode, uint32_t inst, uint32_t 
 struct LightRec { float x, y, z, intensity; };
 struct MaterialRec { float r, g, b; uint32_t type; uint32_t smooth; float ior; };
 
-// Lambert + one shadow ray per light (mode 100): extension, specified by oracle/crt_oracle.c shade_lambert
-template <bool COUNT, int BLOCK>
-__device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* nodes, const float4* tris, const Ray& r,
-                                           const Hit& h, int* stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
+// Surface at a closest hit (oracle: surface_at): hit point, shading normal flipped to face the ray, material
+struct Surface {
+    F3 P, N, albedo;
+    uint32_t mtype;
+    bool entering;
+    float ior;
+};
+
+__device__ __forceinline__ Surface surfaceAt(const RenderParams& p, const float4* tris, const Ray& r, const Hit& h)
 {
+    Surface sf;
     const float4* T = tris + 3 * static_cast<size_t>(h.tri);
     const float4 tb = T[1], tc = T[2];
     const float* S = reinterpret_cast<const float*>(p.shade) + 12 * static_cast<size_t>(h.tri);
     const uint32_t material = __float_as_uint(S[9]);
-    const F3 P = f3(r.o.x + r.d.x * h.t, r.o.y + r.d.y * h.t, r.o.z + r.d.z * h.t);
-    F3 albedo = f3(1.0f, 1.0f, 1.0f);
+    sf.P = f3(r.o.x + r.d.x * h.t, r.o.y + r.d.y * h.t, r.o.z + r.d.z * h.t);
+    sf.albedo = f3(1.0f, 1.0f, 1.0f);
+    sf.mtype = 1u;
+    sf.ior = 1.0f;
     bool smooth = false;
     if (material < p.n_mats) {
         const MaterialRec* M = reinterpret_cast<const MaterialRec*>(p.mats) + material;
-        albedo = f3(M->r, M->g, M->b);
+        sf.albedo = f3(M->r, M->g, M->b);
         smooth = M->smooth != 0;
+        sf.mtype = M->type;
+        sf.ior = M->ior;
     }
     F3 N = cross3(f3(tb.x, tb.y, tb.z), f3(tc.x, tc.y, tc.z));
     if (smooth) {
@@ -343,8 +358,25 @@ __device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* 
         if (dot3(Ns, Ns) > 0.0f) N = Ns;
     }
     N = normalize3(N);
-    if (dot3(N, r.d) > 0.0f) N = f3(-N.x, -N.y, -N.z);
-    const F3 Po = f3(fmaf(N.x, kShadowBias, P.x), fmaf(N.y, kShadowBias, P.y), fmaf(N.z, kShadowBias, P.z));
+    sf.entering = true;
+    if (dot3(N, r.d) > 0.0f) {
+        N = f3(-N.x, -N.y, -N.z);
+        sf.entering = false;
+    }
+    sf.N = N;
+    return sf;
+}
+
+__device__ __forceinline__ F3 biasPoint(F3 P, F3 N, float bias)
+{
+    return f3(fmaf(N.x, bias, P.x), fmaf(N.y, bias, P.y), fmaf(N.z, bias, P.z));
+}
+
+// direct light at Po: one any-hit shadow ray per light with a positive cosine (oracle: direct_light)
+template <bool COUNT, int BLOCK>
+__device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* nodes, const float4* tris, F3 Po, F3 N, F3 albedo,
+                                          int* stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
+{
     F3 rgb = f3(0.0f, 0.0f, 0.0f);
     const LightRec* lights = reinterpret_cast<const LightRec*>(p.lights);
     for (uint32_t li = 0; li < p.n_lights; li++) {
@@ -370,14 +402,109 @@ __device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* 
     return rgb;
 }
 
+// mode 100: Lambert + one shadow ray per light, every material treated as diffuse (oracle: shade_lambert)
+template <bool COUNT, int BLOCK>
+__device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* nodes, const float4* tris, const Ray& r,
+                                           const Hit& h, int* stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
+{
+    const Surface sf = surfaceAt(p, tris, r, h);
+    return directLight<COUNT, BLOCK>(p, nodes, tris, biasPoint(sf.P, sf.N, kShadowBias), sf.N, sf.albedo, stack, iters, cntNodes, cntTris, cntShadow);
+}
+
+// ---- mode 200: path tracing (oracle: trace_path). Counter-based RNG keyed by (pixel, sample, seed).
+__device__ __forceinline__ uint32_t pcgHash(uint32_t v)
+{
+    const uint32_t state = v * 747796405u + 2891336453u;
+    const uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+__device__ __forceinline__ float rngNext(uint32_t& st)
+{
+    st = pcgHash(st);
+    return static_cast<float>(st >> 8) * 0x1p-24f;
+}
+
+template <bool COUNT, int BLOCK>
+__device__ __forceinline__ F3 tracePath(const RenderParams& p, const float4* nodes, const float4* tris, uint32_t px, uint32_t py,
+                                        uint32_t pix, uint32_t sample, int* stack, Hit& firstHit, uint32_t& iters,
+                                        uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow, uint32_t& cntClosest)
+{
+    uint32_t rng = pcgHash(pix ^ pcgHash(sample + pcgHash(p.seed)));
+    const float jx = rngNext(rng), jy = rngNext(rng);
+    Ray r = makeRay(f3(p.pos[0], p.pos[1], p.pos[2]), rayDirJ(p.rot, px, py, jx, jy, static_cast<float>(p.width), static_cast<float>(p.height)));
+    F3 L = f3(0.0f, 0.0f, 0.0f), thr = f3(1.0f, 1.0f, 1.0f);
+    const F3 miss = f3(p.miss[0], p.miss[1], p.miss[2]);
+    float tmin = kTMin;
+    for (uint32_t bounce = 0;; bounce++) {
+        Hit h;
+        if (COUNT) cntClosest++;
+        traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, tmin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, iters, cntNodes, cntTris);
+        if (bounce == 0 && sample == 0) firstHit = h;
+        if (!(h.t < kTMax)) {
+            L = f3(fmaf(thr.x, miss.x, L.x), fmaf(thr.y, miss.y, L.y), fmaf(thr.z, miss.z, L.z));
+            break;
+        }
+        const Surface sf = surfaceAt(p, tris, r, h);
+        tmin = 0.0f;
+        if (sf.mtype == 4u) { // CONSTANT
+            L = f3(fmaf(thr.x, sf.albedo.x, L.x), fmaf(thr.y, sf.albedo.y, L.y), fmaf(thr.z, sf.albedo.z, L.z));
+            break;
+        }
+        if (sf.mtype == 2u) { // REFLECTIVE
+            if (bounce == p.max_bounces) break;
+            const float k = 2.0f * dot3(r.d, sf.N);
+            const F3 d = normalize3(f3(fmaf(-k, sf.N.x, r.d.x), fmaf(-k, sf.N.y, r.d.y), fmaf(-k, sf.N.z, r.d.z)));
+            thr = f3(thr.x * sf.albedo.x, thr.y * sf.albedo.y, thr.z * sf.albedo.z);
+            r = makeRay(biasPoint(sf.P, sf.N, kShadowBias), d);
+            continue;
+        }
+        if (sf.mtype == 3u) { // REFRACTIVE
+            if (bounce == p.max_bounces) break;
+            const float eta = sf.entering ? 1.0f / sf.ior : sf.ior;
+            const float cosi = -dot3(r.d, sf.N);
+            const float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+            F3 d, o;
+            if (k < 0.0f) {
+                const float m = 2.0f * dot3(r.d, sf.N);
+                d = f3(fmaf(-m, sf.N.x, r.d.x), fmaf(-m, sf.N.y, r.d.y), fmaf(-m, sf.N.z, r.d.z));
+                o = biasPoint(sf.P, sf.N, kShadowBias);
+            } else {
+                const float m = eta * cosi - sqrtf(k);
+                d = f3(fmaf(m, sf.N.x, eta * r.d.x), fmaf(m, sf.N.y, eta * r.d.y), fmaf(m, sf.N.z, eta * r.d.z));
+                o = biasPoint(sf.P, sf.N, -kShadowBias);
+            }
+            r = makeRay(o, normalize3(d));
+            continue;
+        }
+        // DIFFUSE and anything else
+        const F3 Po = biasPoint(sf.P, sf.N, kShadowBias);
+        const F3 Ld = directLight<COUNT, BLOCK>(p, nodes, tris, Po, sf.N, sf.albedo, stack, iters, cntNodes, cntTris, cntShadow);
+        L = f3(fmaf(thr.x, Ld.x, L.x), fmaf(thr.y, Ld.y, L.y), fmaf(thr.z, Ld.z, L.z));
+        if (bounce == p.max_bounces) break;
+        const float u1 = rngNext(rng), u2 = rngNext(rng);
+        const float rr = sqrtf(u1), phi = 6.28318530717958648f * u2;
+        const float lx = rr * sinContract(phi + 1.57079632679489662f), ly = rr * sinContract(phi), lz = sqrtf(fmaxf(0.0f, 1.0f - u1));
+        const float sg = copysignf(1.0f, sf.N.z);
+        const float a = -1.0f / (sg + sf.N.z);
+        const float b = sf.N.x * sf.N.y * a;
+        const F3 T = f3(1.0f + sg * sf.N.x * sf.N.x * a, sg * b, -sg * sf.N.x);
+        const F3 B = f3(b, sg + sf.N.y * sf.N.y * a, -sf.N.y);
+        const F3 d = f3(fmaf(lz, sf.N.x, fmaf(ly, B.x, lx * T.x)), fmaf(lz, sf.N.y, fmaf(ly, B.y, lx * T.y)),
+                        fmaf(lz, sf.N.z, fmaf(ly, B.z, lx * T.z)));
+        thr = f3(thr.x * sf.albedo.x, thr.y * sf.albedo.y, thr.z * sf.albedo.z);
+        r = makeRay(Po, normalize3(d));
+    }
+    return L;
+}
+
 __device__ __forceinline__ uint32_t waveSum(uint32_t v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
-template <bool COUNT, int BLOCK>
-__global__ __launch_bounds__(BLOCK) void renderKernel(const RenderParams p)
+template <bool COUNT, bool PATH>
+__global__ __launch_bounds__(64) void renderKernel(const RenderParams p)
 {
     extern __shared__ int s_stack[]; // stack_entries x 256 dwords, sized at launch from the BVH depth
     unsigned long long t_start = 0;
@@ -430,27 +557,45 @@ __global__ __launch_bounds__(BLOCK) void renderKernel(const RenderParams p)
     const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
     const bool active = (px < p.width) & (py < p.height);
 
-    uint32_t cntNodes = 0, cntTris = 0, cntShadow = 0;
+    uint32_t cntNodes = 0, cntTris = 0, cntShadow = 0, cntClosest = 0;
     uint32_t iters = 0; // traversal-loop iterations of this wavefront = its critical path, fed back as next frame's cost
     if (active) {
         const float4* nodes = reinterpret_cast<const float4*>(p.nodes);
         const float4* tris = reinterpret_cast<const float4*>(p.tris);
         int* stack = s_stack + tid;
 
-        const F3 o = f3(p.pos[0], p.pos[1], p.pos[2]);
-        const Ray r = makeRay(o, rayDir(p.rot, px, py, static_cast<float>(p.width), static_cast<float>(p.height)));
-        Hit h;
-        traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, iters, cntNodes, cntTris);
-
-        F3 col = f3(p.miss[0], p.miss[1], p.miss[2]); // miss shader (hlsl:72-76)
+        constexpr int BLOCK = 64;
+        F3 col;
         uint32_t inst = 0xFFFFFFFFu, prim = 0xFFFFFFFFu;
+        Hit h;
+        if (PATH) {
+            // mode 200: spp jittered samples averaged; the hit outputs report sample 0's camera ray
+            const uint32_t pixId = py * p.width + px;
+            F3 acc = f3(0.0f, 0.0f, 0.0f);
+            h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
+            for (uint32_t sm = 0; sm < p.spp; sm++) {
+                const F3 Ls = tracePath<COUNT, BLOCK>(p, nodes, tris, px, py, pixId, sm, stack, h, iters, cntNodes, cntTris, cntShadow, cntClosest);
+                acc = f3(acc.x + Ls.x, acc.y + Ls.y, acc.z + Ls.z);
+            }
+            const float inv = 1.0f / static_cast<float>(p.spp);
+            col = f3(acc.x * inv, acc.y * inv, acc.z * inv);
+        } else {
+            const F3 o = f3(p.pos[0], p.pos[1], p.pos[2]);
+            const Ray r = makeRay(o, rayDir(p.rot, px, py, static_cast<float>(p.width), static_cast<float>(p.height)));
+            if (COUNT) cntClosest++;
+            traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, iters, cntNodes, cntTris);
+            col = f3(p.miss[0], p.miss[1], p.miss[2]); // miss shader (hlsl:72-76)
+            if (h.t < kTMax) {
+                const float4* T = tris + 3 * static_cast<size_t>(h.tri);
+                if (p.mode >= 100u) col = shadeLambert<COUNT, BLOCK>(p, nodes, tris, r, h, stack, iters, cntNodes, cntTris, cntShadow);
+                else col = shadeDebug(p.mode, __float_as_uint(T[0].w), __float_as_uint(T[1].w), h.t, h.u, h.v, r.o, r.d);
+            }
+        }
         const bool hit = h.t < kTMax;
         if (hit) {
             const float4* T = tris + 3 * static_cast<size_t>(h.tri);
             inst = __float_as_uint(T[0].w);
             prim = __float_as_uint(T[1].w);
-            if (p.mode >= 100u) col = shadeLambert<COUNT, BLOCK>(p, nodes, tris, r, h, stack, iters, cntNodes, cntTris, cntShadow);
-            else col = shadeDebug(p.mode, inst, prim, h.t, h.u, h.v, r.o, r.d);
         }
 
         const uint32_t packed = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
@@ -478,11 +623,12 @@ __global__ __launch_bounds__(BLOCK) void renderKernel(const RenderParams p)
         p.timeline[3 * static_cast<size_t>(blockIdx.x) + 2] = (static_cast<unsigned long long>(xcc) << 32) | (tile_y << 16) | tile_x;
     }
     if (COUNT) {
-        const uint32_t a = waveSum(cntNodes), c = waveSum(cntTris), s = waveSum(cntShadow);
+        const uint32_t a = waveSum(cntNodes), c = waveSum(cntTris), s = waveSum(cntShadow), q = waveSum(cntClosest);
         if (lane == 0) {
             atomicAdd(&p.counters[0], static_cast<unsigned long long>(a));
             atomicAdd(&p.counters[1], static_cast<unsigned long long>(c));
             atomicAdd(&p.counters[2], static_cast<unsigned long long>(s));
+            atomicAdd(&p.counters[3], static_cast<unsigned long long>(q));
         }
     }
 }
@@ -517,8 +663,13 @@ int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream)
     const uint32_t n = renderUnitCount(p) / 4u;
     const dim3 grid(n * 4u), block(64);
     const size_t lds = static_cast<size_t>(p.stack_entries) * 64u * sizeof(int);
-    if (counting) hipLaunchKernelGGL((renderKernel<true, 64>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((renderKernel<false, 64>), grid, block, lds, stream, p);
+    if (p.mode >= 200u) {
+        if (counting) hipLaunchKernelGGL((renderKernel<true, true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((renderKernel<false, true>), grid, block, lds, stream, p);
+    } else {
+        if (counting) hipLaunchKernelGGL((renderKernel<true, false>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((renderKernel<false, false>), grid, block, lds, stream, p);
+    }
     return static_cast<int>(hipGetLastError());
 }
 

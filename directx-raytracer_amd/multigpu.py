@@ -23,8 +23,8 @@ def gather_frame(staging, w, h, untile, gathered=None):
     n = dist.get_world_size() if dist.is_initialized() else 1
     if gathered is None:
         gathered = torch.empty(n * staging.numel(), dtype=staging.dtype, device=staging.device)
-    if n == 1:
+    if not dist.is_initialized():
         gathered.copy_(staging)
     else:
-        dist.all_gather_into_tensor(gathered, staging)
+        dist.all_gather_into_tensor(gathered, staging)  # also with one rank: same code path as N > 1
     return untile(gathered)

@@ -48,6 +48,7 @@ enum {
 #define CRT_MODE_DISTANCE 5u
 #define CRT_MODE_CHECKER 6u
 #define CRT_MODE_LAMBERT 100u /* Lambert + one shadow ray per light (BASELINE.json north_star) */
+#define CRT_MODE_PATH 200u    /* path tracing: options "spp" (default 4), "max_bounces" (3), "seed" (1234); BASELINE.json configs[4] */
 
 /* ---- geometry handed over at upload: exactly what createVertexBuffers / createIndexBuffers memcpy ----
  * (R/DXRTRenderer.cpp:391-392,411 and :314-315,334): float xyz stride 12, uint32 indices, mesh ordinal
@@ -76,7 +77,7 @@ typedef struct crt_bvh_shade { float n0[3], n1[3], n2[3]; uint32_t material; uin
 typedef struct crt_frame_stats {
     double kernel_ms;        /* HIP-event time of the render kernel(s) on the context's stream */
     double total_ms;         /* wall time of the call (includes D2H copies when host outputs are requested) */
-    uint64_t rays_primary;   /* = pixels rendered by this call */
+    uint64_t rays_primary;   /* closest-hit rays: pixels rendered by this call (x spp + bounce rays in mode 200, exact when counting) */
     uint64_t rays_shadow;    /* counted only when counting is enabled, else 0 */
     uint64_t nodes_visited;  /* idem: 64-byte node records fetched, summed over all rays */
     uint64_t tris_tested;    /* idem: 48-byte triangle records fetched */
@@ -138,7 +139,9 @@ int crt_render_tiles_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint3
 int crt_untile_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_ranks,
                       const void* d_gathered, void* d_rgba8_rowmajor);
 
-/* tuning knobs (speed only, results never change). "inner_min" 1..65: wave scheduling of the traversal loop */
+/* options. Rendering parameters of mode 200: "spp", "max_bounces", "seed". Tuning knobs (speed only, results never
+ * change): "inner_min" 1..65 wave scheduling of the traversal loop, "xcd_group", "adaptive_order" 0/1, "boost_units",
+ * "stack_entries" (0 = from the BVH depth). Diagnostics: "timeline" 0/1. */
 int crt_set_option(crt_ctx* ctx, const char* name, int value);
 
 /* diagnostics: with option "timeline" = 1 and counting enabled, a render records per workgroup {start, end} on the

@@ -531,10 +531,10 @@ static int brute_any(const oracle_scene* s, const ray* r, float tmin, float tmax
  * rayGen (hlsl:21-55).  The reference hard-codes width=1920,height=1080 (hlsl:24-25); here they are
  * parameters, used in the same float expressions.
  * ---------------------------------------------------------------------------------------------- */
-static inline v3 ray_dir(const float rot[9], uint32_t px, uint32_t py, float width, float height)
+static inline v3 ray_dir_j(const float rot[9], uint32_t px, uint32_t py, float jx, float jy, float width, float height)
 {
     float x = (float)px, y = (float)py;
-    x += 0.5f; y += 0.5f;            /* hlsl:35-36 */
+    x += jx; y += jy;                /* hlsl:35-36 with 0.5, 0.5; the path tracer jitters inside the pixel */
     x /= width; y /= height;         /* hlsl:38-39 */
     x = (2.0f * x) - 1.0f;           /* hlsl:41 */
     y = 1.0f - (2.0f * y);           /* hlsl:42 */
@@ -545,6 +545,11 @@ static inline v3 ray_dir(const float rot[9], uint32_t px, uint32_t py, float wid
                     v3_dot(v3_make(rot[3], rot[4], rot[5]), dc),
                     v3_dot(v3_make(rot[6], rot[7], rot[8]), dc));
     return v3_normalize(dw);
+}
+
+static inline v3 ray_dir(const float rot[9], uint32_t px, uint32_t py, float width, float height)
+{
+    return ray_dir_j(rot, px, py, 0.5f, 0.5f, width, height);
 }
 
 void oracle_ray_dir(const float rot[9], uint32_t px, uint32_t py, uint32_t w, uint32_t h, float out_dir[3])
@@ -622,20 +627,25 @@ int oracle_intersect_tri(const float o[3], const float d[3], const float v0[3], 
     return tri_test(&r, &T, tmin, t, u, v) & (*t < tmax);
 }
 
-/* Lambert + one shadow ray per light (mode 100). NOT IN THE REFERENCE: the reference parses lights and
- * materials (R/CRTLight.h:4-16, R/CRTMaterial.h:4-36) but never evaluates them; this is the build's
- * specification of BASELINE.json's "Lambert ... + shadow rays" (SURVEY.md section 8 row a13). */
-static v3 shade_lambert(const oracle_scene* s, const ray* r, const hit_rec* h, int brute, trav_count* c, uint64_t* n_shadow)
+/* Surface at a closest hit, shared by mode 100 and the path tracer: hit point, shading normal (face normal, or the
+ * barycentric blend of the CRTMesh vertex normals for smooth_shading materials), flipped to face the ray, material. */
+typedef struct { v3 P, N; v3 albedo; uint32_t mtype; int entering; float ior; } surface;
+
+static void surface_at(const oracle_scene* s, const ray* r, const hit_rec* h, surface* sf)
 {
     const oracle_tri* T = &s->tris[h->tri];
     const oracle_shade* S = &s->shade[h->tri];
-    v3 P = v3_make(r->o.x + r->d.x * h->t, r->o.y + r->d.y * h->t, r->o.z + r->d.z * h->t);
-    v3 albedo = v3_make(1.0f, 1.0f, 1.0f);
+    sf->P = v3_make(r->o.x + r->d.x * h->t, r->o.y + r->d.y * h->t, r->o.z + r->d.z * h->t);
+    sf->albedo = v3_make(1.0f, 1.0f, 1.0f);
+    sf->mtype = 1; /* DIFFUSE */
+    sf->ior = 1.0f;
     int smooth = 0;
     if (S->material < s->n_mats) {
         const oracle_material* M = &s->mats[S->material];
-        albedo = v3_make(M->albedo[0], M->albedo[1], M->albedo[2]);
+        sf->albedo = v3_make(M->albedo[0], M->albedo[1], M->albedo[2]);
         smooth = M->smooth != 0;
+        sf->mtype = M->type;
+        sf->ior = M->ior;
     }
     v3 N = v3_cross(v3_make(T->e1[0], T->e1[1], T->e1[2]), v3_make(T->e2[0], T->e2[1], T->e2[2]));
     if (smooth) {
@@ -646,8 +656,16 @@ static v3 shade_lambert(const oracle_scene* s, const ray* r, const hit_rec* h, i
         if (v3_dot(Ns, Ns) > 0.0f) N = Ns; /* zero / missing normals (NaN compares false) -> face normal */
     }
     N = v3_normalize(N);
-    if (v3_dot(N, r->d) > 0.0f) N = v3_make(-N.x, -N.y, -N.z); /* two sided */
-    v3 Po = v3_make(fmaf(N.x, SHADOW_BIAS, P.x), fmaf(N.y, SHADOW_BIAS, P.y), fmaf(N.z, SHADOW_BIAS, P.z));
+    sf->entering = 1;
+    if (v3_dot(N, r->d) > 0.0f) { N = v3_make(-N.x, -N.y, -N.z); sf->entering = 0; } /* two sided */
+    sf->N = N;
+}
+
+/* direct light at Po with normal N: one shadow ray per light whose cosine is positive (BASELINE.json north_star's
+ * "Lambert ... + shadow rays"; lights and materials: R/CRTLight.h:4-16, R/CRTMaterial.h:4-36, parsed but never
+ * evaluated by the reference -- SURVEY.md section 8 row a13: NOT IN THE REFERENCE, the build's specification) */
+static v3 direct_light(const oracle_scene* s, v3 Po, v3 N, v3 albedo, int brute, trav_count* c, uint64_t* n_shadow)
+{
     v3 rgb = v3_make(0.0f, 0.0f, 0.0f);
     for (uint32_t li = 0; li < s->n_lights; li++) {
         const oracle_light* L = &s->lights[li];
@@ -671,6 +689,118 @@ static v3 shade_lambert(const oracle_scene* s, const ray* r, const hit_rec* h, i
         }
     }
     return rgb;
+}
+
+static inline v3 bias_point(v3 P, v3 N, float bias)
+{
+    return v3_make(fmaf(N.x, bias, P.x), fmaf(N.y, bias, P.y), fmaf(N.z, bias, P.z));
+}
+
+/* mode 100: Lambert with every material treated as diffuse */
+static v3 shade_lambert(const oracle_scene* s, const ray* r, const hit_rec* h, int brute, trav_count* c, uint64_t* n_shadow)
+{
+    surface sf;
+    surface_at(s, r, h, &sf);
+    return direct_light(s, bias_point(sf.P, sf.N, SHADOW_BIAS), sf.N, sf.albedo, brute, c, n_shadow);
+}
+
+/* ------------------------------------------------------------------------------------------------
+ * mode 200: path tracing, spp samples per pixel, up to max_bounces bounces (BASELINE.json configs[4]:
+ * "4 spp path-traced (3 bounces)").  NOT IN THE REFERENCE (MaxTraceRecursionDepth = 1, one TraceRay per pixel,
+ * R/DXRTRenderer.cpp:1172): build-defined, SURVEY.md section 8 row a13.  Counter-based RNG keyed by
+ * (pixel, sample, seed) so CPU and GPU draw the same numbers in the same order.
+ * ---------------------------------------------------------------------------------------------- */
+static uint32_t g_path_spp = 4, g_path_bounces = 3, g_path_seed = 1234;
+void oracle_set_path_params(uint32_t spp, uint32_t max_bounces, uint32_t seed)
+{
+    g_path_spp = spp ? spp : 1; g_path_bounces = max_bounces; g_path_seed = seed;
+}
+
+static inline uint32_t pcg_hash(uint32_t v)
+{
+    uint32_t state = v * 747796405u + 2891336453u;
+    uint32_t word = ((state >> ((state >> 28u) + 4u)) ^ state) * 277803737u;
+    return (word >> 22u) ^ word;
+}
+static inline float rng_next(uint32_t* st) /* uniform in [0,1), 24 bits */
+{
+    *st = pcg_hash(*st);
+    return (float)(*st >> 8) * 0x1p-24f;
+}
+
+static v3 trace_path(const oracle_scene* s, const float rot[9], v3 cam, uint32_t px, uint32_t py, float width, float height,
+                     uint32_t pix, uint32_t sample, v3 miss, int brute, trav_count* c, uint64_t* n_closest, uint64_t* n_shadow,
+                     hit_rec* first_hit)
+{
+    uint32_t rng = pcg_hash(pix ^ pcg_hash(sample + pcg_hash(g_path_seed)));
+    const float jx = rng_next(&rng), jy = rng_next(&rng);
+    ray r;
+    ray_setup(&r, cam, ray_dir_j(rot, px, py, jx, jy, width, height));
+    v3 L = v3_make(0.0f, 0.0f, 0.0f), thr = v3_make(1.0f, 1.0f, 1.0f);
+    float tmin = RAY_TMIN;
+    for (uint32_t bounce = 0;; bounce++) {
+        hit_rec h;
+        (*n_closest)++;
+        if (brute) brute_closest(s, &r, tmin, RAY_TMAX, &h, c);
+        else trace_closest(s, &r, tmin, RAY_TMAX, &h, c);
+        if (bounce == 0 && first_hit) *first_hit = h;
+        if (!h.hit) {
+            L = v3_make(fmaf(thr.x, miss.x, L.x), fmaf(thr.y, miss.y, L.y), fmaf(thr.z, miss.z, L.z));
+            break;
+        }
+        surface sf;
+        surface_at(s, &r, &h, &sf);
+        tmin = 0.0f; /* secondary rays start from biased origins */
+        if (sf.mtype == 4u) { /* CONSTANT: emits its albedo, ends the path */
+            L = v3_make(fmaf(thr.x, sf.albedo.x, L.x), fmaf(thr.y, sf.albedo.y, L.y), fmaf(thr.z, sf.albedo.z, L.z));
+            break;
+        }
+        if (sf.mtype == 2u) { /* REFLECTIVE: perfect mirror */
+            if (bounce == g_path_bounces) break;
+            float k = 2.0f * v3_dot(r.d, sf.N);
+            v3 d = v3_normalize(v3_make(fmaf(-k, sf.N.x, r.d.x), fmaf(-k, sf.N.y, r.d.y), fmaf(-k, sf.N.z, r.d.z)));
+            thr = v3_make(thr.x * sf.albedo.x, thr.y * sf.albedo.y, thr.z * sf.albedo.z);
+            ray_setup(&r, bias_point(sf.P, sf.N, SHADOW_BIAS), d);
+            continue;
+        }
+        if (sf.mtype == 3u) { /* REFRACTIVE: Snell, total internal reflection when there is no transmitted ray */
+            if (bounce == g_path_bounces) break;
+            float eta = sf.entering ? 1.0f / sf.ior : sf.ior;
+            float cosi = -v3_dot(r.d, sf.N);
+            float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+            v3 d, o;
+            if (k < 0.0f) {
+                float m = 2.0f * v3_dot(r.d, sf.N);
+                d = v3_make(fmaf(-m, sf.N.x, r.d.x), fmaf(-m, sf.N.y, r.d.y), fmaf(-m, sf.N.z, r.d.z));
+                o = bias_point(sf.P, sf.N, SHADOW_BIAS);
+            } else {
+                float m = eta * cosi - sqrtf(k);
+                d = v3_make(fmaf(m, sf.N.x, eta * r.d.x), fmaf(m, sf.N.y, eta * r.d.y), fmaf(m, sf.N.z, eta * r.d.z));
+                o = bias_point(sf.P, sf.N, -SHADOW_BIAS);
+            }
+            ray_setup(&r, o, v3_normalize(d));
+            continue;
+        }
+        /* DIFFUSE (and anything else): direct light now, then a cosine-weighted bounce */
+        v3 Po = bias_point(sf.P, sf.N, SHADOW_BIAS);
+        v3 Ld = direct_light(s, Po, sf.N, sf.albedo, brute, c, n_shadow);
+        L = v3_make(fmaf(thr.x, Ld.x, L.x), fmaf(thr.y, Ld.y, L.y), fmaf(thr.z, Ld.z, L.z));
+        if (bounce == g_path_bounces) break;
+        float u1 = rng_next(&rng), u2 = rng_next(&rng);
+        float rr = sqrtf(u1), phi = 6.28318530717958648f * u2;
+        float lx = rr * oracle_sinf(phi + 1.57079632679489662f), ly = rr * oracle_sinf(phi), lz = sqrtf(fmaxf(0.0f, 1.0f - u1));
+        /* orthonormal basis around N (Duff et al. 2017, branchless) */
+        float sg = copysignf(1.0f, sf.N.z);
+        float a = -1.0f / (sg + sf.N.z);
+        float b = sf.N.x * sf.N.y * a;
+        v3 T = v3_make(1.0f + sg * sf.N.x * sf.N.x * a, sg * b, -sg * sf.N.x);
+        v3 B = v3_make(b, sg + sf.N.y * sf.N.y * a, -sf.N.y);
+        v3 d = v3_make(fmaf(lz, sf.N.x, fmaf(ly, B.x, lx * T.x)), fmaf(lz, sf.N.y, fmaf(ly, B.y, lx * T.y)),
+                       fmaf(lz, sf.N.z, fmaf(ly, B.z, lx * T.z)));
+        thr = v3_make(thr.x * sf.albedo.x, thr.y * sf.albedo.y, thr.z * sf.albedo.z);
+        ray_setup(&r, Po, v3_normalize(d));
+    }
+    return L;
 }
 
 static uint32_t* g_cost_sp;
@@ -702,21 +832,45 @@ int oracle_render(const oracle_scene* s, const float pos[3], const float rot[9],
     const v3 o = v3_make(pos[0], pos[1], pos[2]);
     const float width = (float)w, height = (float)h;
     const v3 miss = miss_rgb ? v3_make(miss_rgb[0], miss_rgb[1], miss_rgb[2]) : v3_make(0.0f, 1.0f, 1.0f); /* hlsl:75 */
-    uint64_t tot_nodes = 0, tot_tris = 0, tot_shadow = 0, tot_primary = 0;
+    uint64_t tot_nodes = 0, tot_tris = 0, tot_shadow = 0, tot_primary = 0, tot_pixels = 0;
     const long n_rows = y_begin < y_end ? (long)((y_end - y_begin + y_step - 1) / y_step) : 0;
 #ifdef _OPENMP
     if (n_threads <= 0) n_threads = omp_get_max_threads();
 #else
     n_threads = 1;
 #endif
-#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : tot_nodes, tot_tris, tot_shadow, tot_primary)
+#pragma omp parallel for schedule(dynamic, 1) num_threads(n_threads) reduction(+ : tot_nodes, tot_tris, tot_shadow, tot_primary, tot_pixels)
     for (long row = 0; row < n_rows; row++) {
         const uint32_t py = y_begin + (uint32_t)row * y_step;
         trav_count c = { 0, 0 };
-        uint64_t n_shadow = 0;
+        uint64_t n_shadow = 0, n_closest = 0;
         for (uint32_t px = 0; px < w; px++) {
             ray r;
             hit_rec hr;
+            const size_t pix = (size_t)py * w + px;
+            if (mode >= ORACLE_MODE_PATH) {
+                /* path tracing: spp jittered samples averaged; hit outputs report sample 0's camera ray */
+                v3 acc = v3_make(0.0f, 0.0f, 0.0f);
+                hit_rec h0;
+                memset(&h0, 0, sizeof(h0));
+                for (uint32_t sm = 0; sm < g_path_spp; sm++) {
+                    v3 Ls = trace_path(s, rot, o, px, py, width, height, (uint32_t)pix, sm, miss, brute_force, &c, &n_closest, &n_shadow,
+                                       sm == 0 ? &h0 : NULL);
+                    acc = v3_make(acc.x + Ls.x, acc.y + Ls.y, acc.z + Ls.z);
+                }
+                const float inv = 1.0f / (float)g_path_spp;
+                v3 col = v3_make(acc.x * inv, acc.y * inv, acc.z * inv);
+                if (rgba8) {
+                    rgba8[4 * pix + 0] = oracle_unorm8(col.x); rgba8[4 * pix + 1] = oracle_unorm8(col.y);
+                    rgba8[4 * pix + 2] = oracle_unorm8(col.z); rgba8[4 * pix + 3] = 255;
+                }
+                if (hit_inst) hit_inst[pix] = h0.hit ? s->tris[h0.tri].inst : ORACLE_MISS;
+                if (hit_prim) hit_prim[pix] = h0.hit ? s->tris[h0.tri].prim : ORACLE_MISS;
+                if (hit_t) hit_t[pix] = h0.hit ? h0.t : RAY_TMAX;
+                if (rgb_f32) { rgb_f32[3 * pix] = col.x; rgb_f32[3 * pix + 1] = col.y; rgb_f32[3 * pix + 2] = col.z; }
+                continue;
+            }
+            n_closest++;
             ray_setup(&r, o, ray_dir(rot, px, py, width, height));
             const trav_count c0 = c;
             if (g_cost_sp) t_max_sp = 0;
@@ -731,7 +885,6 @@ int oracle_render(const oracle_scene* s, const float pos[3], const float rot[9],
                 if (mode >= ORACLE_MODE_LAMBERT) col = shade_lambert(s, &r, &hr, brute_force, &c, &n_shadow);
                 else col = shade_debug(mode, inst, prim, hr.t, hr.u, hr.v, r.o, r.d);
             }
-            const size_t pix = (size_t)py * w + px;
             if (g_cost_sp) g_cost_sp[pix] = (uint32_t)t_max_sp;
             if (g_cost_pn) {
                 g_cost_pn[pix] = (uint32_t)(c1.nodes - c0.nodes); g_cost_pt[pix] = (uint32_t)(c1.tris - c0.tris);
@@ -748,12 +901,12 @@ int oracle_render(const oracle_scene* s, const float pos[3], const float rot[9],
             if (hit_t) hit_t[pix] = hr.hit ? hr.t : RAY_TMAX;
             if (rgb_f32) { rgb_f32[3 * pix] = col.x; rgb_f32[3 * pix + 1] = col.y; rgb_f32[3 * pix + 2] = col.z; }
         }
-        tot_nodes += c.nodes; tot_tris += c.tris; tot_shadow += n_shadow; tot_primary += w;
+        tot_nodes += c.nodes; tot_tris += c.tris; tot_shadow += n_shadow; tot_primary += n_closest; tot_pixels += w;
     }
     if (stats) {
         stats->rays_primary = tot_primary; stats->rays_shadow = tot_shadow;
         stats->nodes_visited = tot_nodes; stats->tris_tested = tot_tris;
-        stats->pixels = tot_primary;
+        stats->pixels = tot_pixels;
     }
     return 0;
 }

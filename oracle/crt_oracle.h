@@ -31,6 +31,7 @@ extern "C" {
 
 #define ORACLE_MISS 0xFFFFFFFFu
 #define ORACLE_MODE_LAMBERT 100u
+#define ORACLE_MODE_PATH 200u
 
 /* 64-byte inner node, both children's boxes stored in the parent. child ref >= 0: inner node index;
  * child ref < 0: leaf, ~ref = (first_triangle << 3) | count (count 0..4). */
@@ -68,7 +69,7 @@ typedef struct oracle_light { float pos[3]; float intensity; } oracle_light;
 typedef struct oracle_material { float albedo[3]; uint32_t type; uint32_t smooth; float ior; } oracle_material;
 
 typedef struct oracle_stats {
-    uint64_t rays_primary, rays_shadow;
+    uint64_t rays_primary, rays_shadow; /* closest-hit rays (camera + bounce) / any-hit shadow rays */
     uint64_t nodes_visited, tris_tested; /* over all rays traced */
     uint64_t pixels;
 } oracle_stats;
@@ -108,6 +109,10 @@ int oracle_render(const oracle_scene* s, const float pos[3], const float rot[9],
                   uint32_t y_begin, uint32_t y_end, uint32_t y_step,
                   uint8_t* rgba8, uint32_t* hit_inst, uint32_t* hit_prim, float* hit_t, float* rgb_f32,
                   oracle_stats* stats, int brute_force, int n_threads);
+
+/* mode 200 parameters (process-wide): samples per pixel, bounces after the camera ray, RNG seed */
+void oracle_set_path_params(uint32_t spp, uint32_t max_bounces, uint32_t seed);
+void oracle_set_stack_output(uint32_t* max_sp);
 
 /* Small pure functions exposed for known-answer tests. */
 void oracle_ray_dir(const float rot[9], uint32_t px, uint32_t py, uint32_t w, uint32_t h, float out_dir[3]);

@@ -12,6 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "libcrt_oracle.so")
 MISS = 0xFFFFFFFF
 MODE_LAMBERT = 100
+MODE_PATH = 200
 
 NODE_DTYPE = np.dtype([("lx0", "f4"), ("lx1", "f4"), ("ly0", "f4"), ("ly1", "f4"),
                        ("rx0", "f4"), ("rx1", "f4"), ("ry0", "f4"), ("ry1", "f4"),
@@ -86,6 +87,9 @@ def lib():
         L.oracle_intersect_tri.restype = C.c_int
         L.oracle_intersect_tri.argtypes = [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_max_threads.restype = C.c_int
+        L.oracle_set_path_params.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oracle_set_cost_outputs.argtypes = [C.c_void_p] * 4
+        L.oracle_set_stack_output.argtypes = [C.c_void_p]
         _lib = L
     return _lib
 
@@ -247,6 +251,11 @@ def intersect_tri(o, d, v0, v1, v2, tmin=0.001, tmax=10000.0):
     v = C.c_float()
     hit = lib().oracle_intersect_tri(*[a.ctypes.data for a in arrs], tmin, tmax, C.byref(t), C.byref(u), C.byref(v))
     return bool(hit), t.value, u.value, v.value
+
+
+def set_path_params(spp=4, max_bounces=3, seed=1234):
+    """mode 200 parameters (process-wide in the oracle)"""
+    lib().oracle_set_path_params(int(spp), int(max_bounces), int(seed))
 
 
 def max_threads():

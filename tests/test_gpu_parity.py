@@ -230,3 +230,55 @@ def test_scheduling_knobs_never_change_results(pkg, oracle, scenes, dragon, rend
         renderer.set_counting(False)
         for name, v in defaults.items():
             renderer.set_option(name, v)
+
+
+def _compare_path(pkg, oracle, renderer, sc, w, h, spp, bounces, seed, miss=(0.0, 0.0, 0.0)):
+    cam = sc["camera"]
+    renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+    renderer.set_camera(cam["position"], cam["matrix"])
+    renderer.set_miss_color(miss)
+    renderer.change_shading_mode(pkg.MODE_PATH)
+    renderer.set_path_params(spp, bounces, seed)
+    renderer.set_counting(True)
+    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    oracle.set_path_params(spp, bounces, seed)
+    try:
+        got = renderer.render_frame(w, h)
+        ref = O.render(cam["position"], cam["matrix"], oracle.MODE_PATH, w, h, miss_rgb=miss)
+    finally:
+        oracle.set_path_params(4, 3, 1234)
+        renderer.set_path_params(4, 3, 1234)
+        renderer.set_counting(False)
+        renderer.set_miss_color((0.0, 1.0, 1.0))
+    for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
+        np.testing.assert_array_equal(got[k], ref[k], err_msg=k)
+    err = np.abs(got["rgb"].astype(np.float64) - ref["rgb"].astype(np.float64))
+    assert np.nanmax(err) <= RGB_TOL
+    assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True), "path-traced rgb not bit-exact"
+    st, rs = got["stats"], ref["stats"]
+    assert (st["rays_primary"], st["rays_shadow"], st["nodes_visited"], st["tris_tested"]) == \
+           (rs["rays_primary"], rs["rays_shadow"], rs["nodes_visited"], rs["tris_tested"])
+    return got
+
+
+def test_path_tracing_cornell_all_material_types(pkg, oracle, scenes, renderer):
+    """mode 200 (BASELINE.json configs[4]: 4 spp, 3 bounces): diffuse + constant (ceiling light) + mirror + glass."""
+    sc = scenes.cornell_box()
+    _compare_path(pkg, oracle, renderer, sc, 256, 256, 4, 3, 1234)
+    sc["materials"][1] = {"albedo": (0.9, 0.9, 0.9), "type": 2}                 # left wall mirror
+    sc["materials"][2] = {"albedo": (1.0, 1.0, 1.0), "type": 3, "ior": 1.5}     # right wall glass
+    got = _compare_path(pkg, oracle, renderer, sc, 200, 120, 3, 5, 42, miss=(0.2, 0.3, 0.4))
+    assert np.isfinite(got["rgb"]).all()
+    _compare_path(pkg, oracle, renderer, sc, 64, 64, 1, 0, 7)                    # no bounces at all
+
+
+def test_path_tracing_dragon_smooth_normals_and_mirror_ground(pkg, oracle, scenes, dragon, renderer):
+    """The shipped scene's own materials: reflective ground (type 2), diffuse smooth-shaded dragon, 4 lights."""
+    _compare_path(pkg, oracle, renderer, _with_normals(scenes, dragon), 640, 360, 4, 3, 1234)
+
+
+def test_path_tracing_large_mesh(pkg, oracle, scenes, renderer):
+    """Path tracing on a 250k-triangle height field at 4K/16 (stand-in for configs[4]'s 5M-triangle 4K frame, which the
+    CPU oracle cannot finish in test time): same kernel, same code paths, incoherent bounce rays."""
+    sc = scenes.heightfield(n=354, n_lights=2)
+    _compare_path(pkg, oracle, renderer, sc, 960, 540, 4, 3, 1234)

@@ -252,3 +252,83 @@ def test_empty_scene_is_all_miss(oracle):
     S = oracle.OracleScene([])
     out = S.render((0, 0, 0), IDENT, 0, 8, 8)
     assert np.all(out["hit_inst"] == oracle.MISS) and np.all(out["rgba8"] == np.uint8([0, 255, 255, 255]))
+
+
+# ------------------------------------------------------------------------------------------ path tracing (mode 200)
+def _pcg_hash(v):
+    state = (v * 747796405 + 2891336453) & 0xFFFFFFFF
+    word = (((state >> ((state >> 28) + 4)) ^ state) * 277803737) & 0xFFFFFFFF
+    return ((word >> 22) ^ word) & 0xFFFFFFFF
+
+
+def test_path_tracer_is_deterministic_and_seeded(oracle, scenes):
+    sc = scenes.cornell_box()
+    cam = sc["camera"]
+    S = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    oracle.set_path_params(4, 3, 1234)
+    a = S.render(cam["position"], cam["matrix"], 200, 96, 96, miss_rgb=(0, 0, 0), n_threads=1)
+    b = S.render(cam["position"], cam["matrix"], 200, 96, 96, miss_rgb=(0, 0, 0), n_threads=4)
+    assert np.array_equal(a["rgb"], b["rgb"]) and a["stats"] == b["stats"]          # independent of threading
+    oracle.set_path_params(4, 3, 99)
+    c = S.render(cam["position"], cam["matrix"], 200, 96, 96, miss_rgb=(0, 0, 0))
+    assert not np.array_equal(a["rgb"], c["rgb"])                                      # seeded
+    oracle.set_path_params(4, 3, 1234)
+    st = a["stats"]
+    assert st["pixels"] == 96 * 96 and st["rays_primary"] >= 4 * 96 * 96 and st["rays_primary"] <= 4 * 4 * 96 * 96
+    assert np.all(np.isfinite(a["rgb"])) and a["rgb"].min() >= 0.0
+    # sample 0's camera ray is jittered inside its pixel: hits agree with the unjittered frame except at silhouettes
+    ref = S.render(cam["position"], cam["matrix"], 3, 96, 96)
+    assert (a["hit_inst"] == ref["hit_inst"]).mean() > 0.97
+
+
+def test_path_tracer_zero_bounces_equals_direct_light_of_jittered_camera_rays(oracle, scenes):
+    """max_bounces = 0: radiance = direct light at the first hit (diffuse), albedo (constant) or miss colour."""
+    sc = scenes.cornell_box()
+    cam = sc["camera"]
+    S = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    oracle.set_path_params(1, 0, 7)
+    a = S.render(cam["position"], cam["matrix"], 200, 64, 64, miss_rgb=(0.25, 0.5, 0.75))
+    oracle.set_path_params(4, 3, 1234)
+    miss = a["hit_inst"] == oracle.MISS
+    np.testing.assert_array_equal(a["rgb"][miss], np.broadcast_to(np.float32([0.25, 0.5, 0.75]), (int(miss.sum()), 3)))
+    light = a["hit_inst"] == 3  # the ceiling quad has a CONSTANT material: its albedo is returned
+    assert light.any()
+    np.testing.assert_array_equal(a["rgb"][light], np.broadcast_to(np.float32([1, 1, 1]), (int(light.sum()), 3)))
+    assert a["stats"]["rays_primary"] == 64 * 64  # no bounce rays
+
+
+def test_path_tracer_brute_force_equals_bvh(oracle, scenes):
+    sc = scenes.cornell_box()
+    sc["materials"][1] = {"albedo": (0.9, 0.9, 0.9), "type": 2}                    # left wall: mirror
+    sc["materials"][2] = {"albedo": (1.0, 1.0, 1.0), "type": 3, "ior": 1.5}        # right wall: glass
+    cam = sc["camera"]
+    S = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    oracle.set_path_params(2, 3, 5)
+    a = S.render(cam["position"], cam["matrix"], 200, 64, 64, miss_rgb=(0.1, 0.1, 0.1))
+    b = S.render(cam["position"], cam["matrix"], 200, 64, 64, miss_rgb=(0.1, 0.1, 0.1), brute_force=True)
+    oracle.set_path_params(4, 3, 1234)
+    for k in ("hit_inst", "hit_prim", "hit_t", "rgb", "rgba8"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["stats"]["rays_primary"] == b["stats"]["rays_primary"] and a["stats"]["rays_shadow"] == b["stats"]["rays_shadow"]
+
+
+def test_rng_known_answers(oracle):
+    """pcg hash (RXS-M-XS 32) restated in Python: the first jitter of pixel 0 / sample 0 / seed 1234 is reproduced
+    through the image: a 1x1 frame's camera ray direction identifies (jx, jy)."""
+    st = _pcg_hash(0 ^ _pcg_hash(0 + _pcg_hash(1234)))
+    st1 = _pcg_hash(st)
+    st2 = _pcg_hash(st1)
+    jx, jy = (st1 >> 8) * 2.0 ** -24, (st2 >> 8) * 2.0 ** -24
+    assert 0 <= jx < 1 and 0 <= jy < 1
+    # a big quad facing an identity camera at z=-2: mode-200 with 0 bounces and a CONSTANT material returns albedo,
+    # and hit_t of sample 0 = 2 / -dir.z of the jittered ray
+    quad = {"vertices": np.float32([(-50, -50, -2), (50, -50, -2), (50, 50, -2), (-50, 50, -2)]), "triangles": [(0, 1, 2), (0, 2, 3)], "material_index": 0}
+    S = oracle.OracleScene([quad], [], [{"albedo": (0.5, 0.25, 0.125), "type": 4}])
+    oracle.set_path_params(1, 0, 1234)
+    out = S.render((0, 0, 0), IDENT, 200, 1, 1)
+    oracle.set_path_params(4, 3, 1234)
+    x = (2 * jx - 1) * 1.0
+    y = 1 - 2 * jy
+    t_exp = 2.0 * math.sqrt(x * x + y * y + 1)
+    assert abs(float(out["hit_t"][0, 0]) - t_exp) < 1e-5
+    np.testing.assert_array_equal(out["rgb"][0, 0], np.float32([0.5, 0.25, 0.125]))
