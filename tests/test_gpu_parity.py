@@ -282,3 +282,76 @@ def test_path_tracing_large_mesh(pkg, oracle, scenes, renderer):
     CPU oracle cannot finish in test time): same kernel, same code paths, incoherent bounce rays."""
     sc = scenes.heightfield(n=354, n_lights=2)
     _compare_path(pkg, oracle, renderer, sc, 960, 540, 4, 3, 1234)
+
+
+def test_c5_full_size_properties(pkg, scenes, renderer):
+    """BASELINE.json configs[4] at full size: 4 999 124-triangle mesh, 3840x2160, 4 spp, 3 bounces.  The CPU oracle
+    needs minutes for this frame, so the full-size run is checked through size-independent properties: determinism
+    (idempotence under a different launch order), tile partition == single launch, structural sanity; the arithmetic
+    itself is pinned bit-exactly against the oracle at smaller sizes above."""
+    import torch
+    sc = scenes.heightfield(n=1581, n_lights=2)
+    assert sum(len(m["triangles"]) for m in sc["meshes"]) == 4999124
+    renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+    info = renderer.bvh_info()
+    assert info["n_tris"] == 4999124 and info["max_depth"] <= 32
+    renderer.set_camera(sc["camera"]["position"], sc["camera"]["matrix"])
+    renderer.change_shading_mode(pkg.MODE_PATH)
+    renderer.set_path_params(4, 3, 1234)
+    w, h = 3840, 2160
+    try:
+        a = torch.zeros(h * w, dtype=torch.int32, device="cuda")
+        b = torch.zeros(h * w, dtype=torch.int32, device="cuda")
+        rgb = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+        renderer.set_counting(True)
+        st = renderer.render_frame_device(w, h, a.data_ptr(), d_rgb=rgb.data_ptr(), stats=True)
+        renderer.set_counting(False)
+        assert st["rays_primary"] >= 4 * w * h and st["rays_shadow"] > 0
+        renderer.render_frame_device(w, h, b.data_ptr())   # second frame runs in the cost-sorted order of the first
+        renderer.synchronize()
+        assert torch.equal(a, b)
+        assert bool(torch.isfinite(rgb).all()) and float(rgb.min()) >= 0.0
+        n = 8
+        slots = pkg.tile_slots(w, h, n)
+        gathered = torch.zeros(n * slots * 256, dtype=torch.int32, device="cuda")
+        for rank in range(n):
+            renderer.render_tiles_device(w, h, rank, n, gathered.data_ptr() + rank * slots * 1024)
+        renderer.untile_device(w, h, n, gathered.data_ptr(), b.data_ptr())
+        renderer.synchronize()
+        assert torch.equal(a, b)
+        alpha = (a.cpu().numpy().view(np.uint32) >> 24)
+        assert np.all(alpha == 255)
+    finally:
+        renderer.set_counting(False)
+        renderer.change_shading_mode(0)
+
+
+def test_headless_cpp_driver_matches_binding(pkg, oracle, scenes, dragon, tmp_path, golden_dir):
+    """crt_render (csrc/crt_render_main.cpp): the C++ host path -- crt::Scene loader, crt::Renderer with DXRTRenderer's
+    methods, scripted camera through the same Camera calls the reference's input handlers make -- produces the frames
+    the oracle predicts for the same camera path."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "crt_render")
+    assert os.path.exists(exe), "crt_render not built"
+    prefix = str(tmp_path / "frame")
+    out = subprocess.run([exe, os.path.join(golden_dir, "dragon.crtscene"), "--mode", "100", "--size", "480x270", "--frames", "3",
+                          "--orbit", "15", "--forward", "1.5", "--out", prefix, "--count"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "Mray/s" in out.stdout and "average kernel" in out.stdout
+    sc = _with_normals(scenes, dragon)
+    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    s = pkg.Scene(os.path.join(golden_dir, "dragon.crtscene"))
+    for f in range(3):
+        if f > 0:
+            s.rotate(15.0, 0.0)
+            s.move_forward(-1.5)
+        pos, rot = s.camera()
+        ref = O.render(pos, rot, 100, 480, 270)["rgba8"][..., :3]
+        raw = open("%s_%d.ppm" % (prefix, f), "rb").read()
+        header_end = raw.index(b"255\n") + 4
+        assert raw[:header_end] == b"P6\n480 270\n255\n"
+        img = np.frombuffer(raw[header_end:], dtype=np.uint8).reshape(270, 480, 3)
+        np.testing.assert_array_equal(img, ref, err_msg="frame %d" % f)
+    # failure is an error message and a non-zero exit code, never an assert/abort
+    bad = subprocess.run([exe, str(tmp_path / "nope.crtscene")], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "cannot open" in bad.stderr
