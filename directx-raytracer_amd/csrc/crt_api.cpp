@@ -63,6 +63,8 @@ struct crt_ctx {
     hipStream_t sideStream = nullptr; // runs the sort of frame k concurrently with the render of frame k+1
     hipEvent_t evRender[2] = { nullptr, nullptr }, evSort[2] = { nullptr, nullptr };
     unsigned long long* dCounters = nullptr;
+    int* dSpill = nullptr; // traversal-stack spill arena (render_kernels.hip Stack)
+    size_t spillBytes = 0;
     unsigned long long* dTimeline = nullptr; // diagnostic: 3 words per workgroup, counting variant only
     size_t timelineWords = 0;
     bool wantTimeline = false;
@@ -147,14 +149,15 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.counters = c->dCounters;
     p.timeline = nullptr;
     p.unit_order = nullptr;
+    p.spill = nullptr;
     p.unit_cost = nullptr;
     p.tune_inner_min = c->tuneInnerMin;
     p.xcd_group = c->tuneXcdGroup;
     p.boost_units = c->tuneBoostUnits;
-    // a ray's stack never holds more entries than the tree is deep; fewer entries = less LDS = more resident waves
-    uint32_t need = c->bvh.maxDepth < 4 ? 4 : c->bvh.maxDepth;
-    need = (need + 1u) & ~1u;
-    p.stack_entries = c->tuneStackEntries ? c->tuneStackEntries : (need > crt::kStackEntries ? crt::kStackEntries : need);
+    // LDS part of the per-lane stack: 24 entries x 64 lanes x 4 B = 6 KB per wavefront -> 26 wavefronts per CU, the measured
+    // optimum (28 and 32 resident wavefronts are 5-10 % slower: L1 thrash); deeper entries (never seen on the test scenes,
+    // possible up to the builder's depth 32) spill to the arena
+    p.stack_entries = c->tuneStackEntries ? c->tuneStackEntries : 24u;
 }
 
 // enqueue one frame; when stats != nullptr, bracket with events, synchronise and fill the timers/counters
@@ -172,6 +175,18 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         }
         HIP_TRY(c, hipMemsetAsync(c->dTimeline, 0, c->timelineWords * sizeof(unsigned long long), c->stream));
         p.timeline = c->dTimeline;
+    }
+    {
+        const size_t need = static_cast<size_t>(crt::renderUnitCount(p)) * 64u * crt::kStackEntries * sizeof(int);
+        if (c->spillBytes < need) {
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            if (c->dSpill) (void)hipFree(c->dSpill);
+            c->dSpill = nullptr;
+            c->spillBytes = 0;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dSpill), need));
+            c->spillBytes = need;
+        }
+        p.spill = c->dSpill;
     }
     // Cost feedback: the lifetimes frame k's wavefronts report are sorted on a side stream WHILE frame k+1 renders and
     // order the launch of frame k+2 (two alternating buffer sets), so the sort never sits on the frame's critical path.
@@ -299,6 +314,7 @@ void crt_destroy(crt_ctx* c)
     for (int i = 0; i < 5; i++)
         if (c->dFrame[i]) (void)hipFree(c->dFrame[i]);
     if (c->dCounters) (void)hipFree(c->dCounters);
+    if (c->dSpill) (void)hipFree(c->dSpill);
     if (c->sideStream) (void)hipStreamSynchronize(c->sideStream);
     for (int i = 0; i < 2; i++) {
         if (c->dUnitCost[i]) (void)hipFree(c->dUnitCost[i]);
@@ -445,7 +461,7 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
         c->orderKey[0] = c->orderKey[1] = 0;
         return CRT_OK;
     }
-    if (std::strcmp(name, "stack_entries") == 0 && (value == 0 || (value >= static_cast<int>(c->bvh.maxDepth) && value <= crt::kStackEntries))) {
+    if (std::strcmp(name, "stack_entries") == 0 && (value == 0 || (value >= 1 && value <= crt::kStackEntries))) {
         c->tuneStackEntries = static_cast<uint32_t>(value);
         return CRT_OK;
     }

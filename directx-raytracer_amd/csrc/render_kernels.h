@@ -31,7 +31,7 @@ struct RenderParams {
     uint32_t n_local_tiles;      // grid size: number of such tiles
     uint32_t staging;            // 0: write row-major frame buffers; 1: rgba8 goes to the tile-major staging buffer
     uint32_t tune_inner_min;     // wave scheduling knob, see traceClosest()
-    uint32_t stack_entries;      // per-lane LDS stack depth (>= BVH depth, <= kStackEntries)
+    uint32_t stack_entries;      // per-lane stack entries kept in LDS; deeper ones go to the spill arena
     uint32_t boost_units;        // with unit_order: the first boost_units (most expensive) work units run at raised priority
     uint32_t xcd_group;          // consecutive tiles of the list handed to one XCD before moving to the next (1..16, power of 2)
     // outputs (device pointers, nullable except rgba8)
@@ -41,6 +41,7 @@ struct RenderParams {
     float* hit_t;
     float* rgb_f32;
     unsigned long long* counters; // [0] nodes fetched, [1] triangles fetched, [2] shadow rays, [3] closest-hit rays; counting variant
+    int* spill;                   // stack spill arena: renderUnitCount() x 64 lanes x kStackEntries ints, rarely touched
     const uint32_t* unit_order;   // nullable: work units sorted by descending cost of the previous frame (launch order)
     uint32_t* unit_cost;          // nullable: per work unit, traversal-loop iterations of its wavefront (this frame)
     unsigned long long* timeline; // counting variant only, nullable: per workgroup {start, end} of s_memrealtime (100 MHz) + XCC id

@@ -127,6 +127,28 @@ __device__ __forceinline__ bool triTest(const Ray& r, const float4 a, const floa
     return (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin);
 }
 
+// Per-lane traversal stack.  The first `cap` entries live in LDS (entry e of lane l at dword e*64+l: conflict free); cap
+// is chosen so that 8 wavefronts per SIMD fit the CU's 160 KB.  No ray of the test scenes ever holds more than 15
+// entries while the trees are 24..26 deep, but the builder allows depth 32, so deeper entries spill to a per-lane slice
+// of a global arena that is never touched otherwise: any tree stays correct with the small LDS footprint.
+struct Stack {
+    int* lds;    // s_stack + lane
+    int* spill;  // arena slice of this lane: kStackEntries - cap entries are ever needed, kStackEntries reserved
+    int cap;     // wave-uniform
+    int sp;
+    __device__ __forceinline__ void push(int v)
+    {
+        if (sp < cap) lds[sp * 64] = v;
+        else spill[sp - cap] = v;
+        sp++;
+    }
+    __device__ __forceinline__ int pop()
+    {
+        sp--;
+        return sp < cap ? lds[sp * 64] : spill[sp - cap];
+    }
+};
+
 struct Hit {
     float t, u, v;
     uint32_t tri; // leaf-order triangle index
@@ -136,8 +158,8 @@ struct Hit {
 // One traversal step for a lane standing on an inner node: fetch the 64-byte record, test both child boxes,
 // descend into the nearer hit child (far one pushed) or pop.
 template <bool COUNT, int BLOCK>
-__device__ __forceinline__ void nodeStep(const float4* __restrict__ nodes, const Ray& r, float tmin, float tcull, int* stack,
-                                         int& cur, int& sp, uint32_t& cntNodes)
+__device__ __forceinline__ void nodeStep(const float4* __restrict__ nodes, const Ray& r, float tmin, float tcull, Stack& stack,
+                                         int& cur, uint32_t& cntNodes)
 {
     const float4* N = nodes + 4 * static_cast<size_t>(cur);
     const float4 n0 = N[0], n1 = N[1], n2 = N[2];
@@ -148,18 +170,16 @@ __device__ __forceinline__ void nodeStep(const float4* __restrict__ nodes, const
     const bool hr = boxTest(n1.x, n1.y, n1.z, n1.w, n2.z, n2.w, r, tmin, tcull, tnr);
     if (hl & hr) {
         const bool rightFirst = tnr < tnl;
-        stack[sp * BLOCK] = rightFirst ? n3.x : n3.y;
-        sp++;
+        stack.push(rightFirst ? n3.x : n3.y);
         cur = rightFirst ? n3.y : n3.x;
     } else if (hl) {
         cur = n3.x;
     } else if (hr) {
         cur = n3.y;
-    } else if (sp == 0) {
+    } else if (stack.sp == 0) {
         cur = kDone;
     } else {
-        sp--;
-        cur = stack[sp * BLOCK];
+        cur = stack.pop();
     }
 }
 
@@ -170,12 +190,12 @@ __device__ __forceinline__ void nodeStep(const float4* __restrict__ nodes, const
 // every lane has one: 47 % of the lanes active on the 1M-triangle frame); 24 measured best (0.67 vs 1.10 ms).
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ void traceClosest(const float4* __restrict__ nodes, const float4* __restrict__ tris,
-                                             uint32_t n_nodes, const Ray& r, float tmin, float tmax, int* stack, int innerMin,
+                                             uint32_t n_nodes, const Ray& r, float tmin, float tmax, Stack& stack, int innerMin,
                                              Hit& h, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris)
 {
     h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
     int cur = n_nodes ? 0 : kDone;
-    int sp = 0;
+    stack.sp = 0;
     float tcull = tmax * kCullPad; // boxes are culled against best_t * pad; changes only when a hit is accepted
     for (;;) {
         const unsigned long long innerMask = __ballot(cur >= 0);
@@ -183,7 +203,7 @@ __device__ __forceinline__ void traceClosest(const float4* __restrict__ nodes, c
         if ((innerMask | leafMask) == 0ull) break;
         if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3); // a wavefront on a long critical path stops queueing behind the others
         if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
-            if (cur >= 0) nodeStep<COUNT, BLOCK>(nodes, r, tmin, tcull, stack, cur, sp, cntNodes);
+            if (cur >= 0) nodeStep<COUNT, BLOCK>(nodes, r, tmin, tcull, stack, cur, cntNodes);
             continue;
         }
         if ((cur < 0) & (cur != kDone)) {
@@ -202,24 +222,19 @@ __device__ __forceinline__ void traceClosest(const float4* __restrict__ nodes, c
                     }
                 }
             }
-            if (sp == 0) {
-                cur = kDone;
-            } else {
-                sp--;
-                cur = stack[sp * BLOCK];
-            }
+            cur = stack.sp == 0 ? kDone : stack.pop();
         }
     }
 }
 
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ bool traceAny(const float4* __restrict__ nodes, const float4* __restrict__ tris,
-                                         uint32_t n_nodes, const Ray& r, float tmin, float tmax, int* stack, int innerMin,
+                                         uint32_t n_nodes, const Ray& r, float tmin, float tmax, Stack& stack, int innerMin,
                                          uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris)
 {
     bool occluded = false;
     int cur = n_nodes ? 0 : kDone;
-    int sp = 0;
+    stack.sp = 0;
     const float tcull = tmax * kCullPad;
     for (;;) {
         const unsigned long long innerMask = __ballot(cur >= 0);
@@ -227,7 +242,7 @@ __device__ __forceinline__ bool traceAny(const float4* __restrict__ nodes, const
         if ((innerMask | leafMask) == 0ull) break;
         if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3);
         if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
-            if (cur >= 0) nodeStep<COUNT, BLOCK>(nodes, r, tmin, tcull, stack, cur, sp, cntNodes);
+            if (cur >= 0) nodeStep<COUNT, BLOCK>(nodes, r, tmin, tcull, stack, cur, cntNodes);
             continue;
         }
         if ((cur < 0) & (cur != kDone)) {
@@ -243,12 +258,7 @@ __device__ __forceinline__ bool traceAny(const float4* __restrict__ nodes, const
                     break;
                 }
             }
-            if (occluded | (sp == 0)) {
-                cur = kDone;
-            } else {
-                sp--;
-                cur = stack[sp * BLOCK];
-            }
+            cur = (occluded | (stack.sp == 0)) ? kDone : stack.pop();
         }
     }
     return occluded;
@@ -375,7 +385,7 @@ __device__ __forceinline__ F3 biasPoint(F3 P, F3 N, float bias)
 // direct light at Po: one any-hit shadow ray per light with a positive cosine (oracle: direct_light)
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* nodes, const float4* tris, F3 Po, F3 N, F3 albedo,
-                                          int* stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
+                                          Stack& stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
 {
     F3 rgb = f3(0.0f, 0.0f, 0.0f);
     const LightRec* lights = reinterpret_cast<const LightRec*>(p.lights);
@@ -405,7 +415,7 @@ __device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* n
 // mode 100: Lambert + one shadow ray per light, every material treated as diffuse (oracle: shade_lambert)
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* nodes, const float4* tris, const Ray& r,
-                                           const Hit& h, int* stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
+                                           const Hit& h, Stack& stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
 {
     const Surface sf = surfaceAt(p, tris, r, h);
     return directLight<COUNT, BLOCK>(p, nodes, tris, biasPoint(sf.P, sf.N, kShadowBias), sf.N, sf.albedo, stack, iters, cntNodes, cntTris, cntShadow);
@@ -426,7 +436,7 @@ __device__ __forceinline__ float rngNext(uint32_t& st)
 
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ F3 tracePath(const RenderParams& p, const float4* nodes, const float4* tris, uint32_t px, uint32_t py,
-                                        uint32_t pix, uint32_t sample, int* stack, Hit& firstHit, uint32_t& iters,
+                                        uint32_t pix, uint32_t sample, Stack& stack, Hit& firstHit, uint32_t& iters,
                                         uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow, uint32_t& cntClosest)
 {
     uint32_t rng = pcgHash(pix ^ pcgHash(sample + pcgHash(p.seed)));
@@ -562,7 +572,11 @@ __global__ __launch_bounds__(64) void renderKernel(const RenderParams p)
     if (active) {
         const float4* nodes = reinterpret_cast<const float4*>(p.nodes);
         const float4* tris = reinterpret_cast<const float4*>(p.tris);
-        int* stack = s_stack + tid;
+        Stack stack;
+        stack.lds = s_stack + tid;
+        stack.spill = p.spill + (static_cast<size_t>(unit) * 64u + tid) * kStackEntries;
+        stack.cap = static_cast<int>(p.stack_entries);
+        stack.sp = 0;
 
         constexpr int BLOCK = 64;
         F3 col;
