@@ -1,0 +1,28 @@
+#!/usr/bin/env python3
+"""A/B two builds of libcrt_hip.so in ONE process (interleaved rounds): tools/ab_lib.py libA.so libB.so [--mode 100]"""
+import argparse, importlib, os, statistics, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import __graft_entry__ as entry
+ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--mode", type=int, default=100)
+ap.add_argument("--rounds", type=int, default=6); ap.add_argument("--frames", type=int, default=20)
+a = ap.parse_args()
+import torch
+pkg = entry.load_package(); scenes = importlib.import_module(entry.PKG_NAME + ".scenes")
+sc = scenes.heightfield(n_lights=1)
+W, H = 1920, 1080
+frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+rs = []
+for path in a.libs:
+    pkg._lib = None; pkg.LIB_PATH = os.path.abspath(path)
+    L = pkg.lib()
+    r = pkg.Renderer(0); r.upload(sc["meshes"], sc["lights"], sc["materials"]); r.set_camera(sc["camera"]["position"], sc["camera"]["matrix"]); r.change_shading_mode(a.mode)
+    rs.append((path, L, r))
+res = {p: [] for p, _, _ in rs}
+for rnd in range(a.rounds + 1):
+    for path, L, r in rs:
+        pkg._lib = L
+        ms = [r.render_frame_device(W, H, frame.data_ptr(), stats=True)["kernel_ms"] for _ in range(a.frames)]
+        if rnd: res[path].append(statistics.median(ms))
+for path in res:
+    print("%-40s median %.4f ms  min %.4f ms" % (os.path.basename(path), statistics.median(res[path]), min(res[path])), flush=True)
