@@ -53,6 +53,7 @@ struct crt_ctx {
     uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
     uint32_t tuneXcdGroup = 16;
     uint32_t tuneBoostUnits = 512;
+    uint32_t debugSkipUnits = 0;
     bool adaptiveOrder = true;     // launch the work units of frame N+1 in descending order of their cost in frame N
     uint32_t* dUnitCost[2] = { nullptr, nullptr };
     uint32_t* dUnitOrder[2] = { nullptr, nullptr };
@@ -154,6 +155,7 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.tune_inner_min = c->tuneInnerMin;
     p.xcd_group = c->tuneXcdGroup;
     p.boost_units = c->tuneBoostUnits;
+    p.debug_skip_units = c->debugSkipUnits;
     // LDS part of the per-lane stack: 24 entries x 64 lanes x 4 B = 6 KB per wavefront -> 26 wavefronts per CU, the measured
     // optimum (28 and 32 resident wavefronts are 5-10 % slower: L1 thrash); deeper entries (never seen on the test scenes,
     // possible up to the builder's depth 32) spill to the arena
@@ -450,6 +452,10 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
     }
     if (std::strcmp(name, "boost_units") == 0 && value >= 0) {
         c->tuneBoostUnits = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "debug_skip_units") == 0 && value >= 0) {
+        c->debugSkipUnits = static_cast<uint32_t>(value);
         return CRT_OK;
     }
     if (std::strcmp(name, "timeline") == 0) {

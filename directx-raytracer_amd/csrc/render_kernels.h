@@ -32,6 +32,7 @@ struct RenderParams {
     uint32_t staging;            // 0: write row-major frame buffers; 1: rgba8 goes to the tile-major staging buffer
     uint32_t tune_inner_min;     // wave scheduling knob, see traceClosest()
     uint32_t stack_entries;      // per-lane stack entries kept in LDS; deeper ones go to the spill arena
+    uint32_t debug_skip_units;   // diagnostics: with unit_order, the first N work units are not rendered
     uint32_t boost_units;        // with unit_order: the first boost_units (most expensive) work units run at raised priority
     uint32_t xcd_group;          // consecutive tiles of the list handed to one XCD before moving to the next (1..16, power of 2)
     // outputs (device pointers, nullable except rgba8)

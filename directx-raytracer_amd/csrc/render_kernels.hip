@@ -611,6 +611,7 @@ __global__ __launch_bounds__(64) void renderKernel(const RenderParams p)
         // the few packets with the longest critical paths bound the frame time even when they start first: let them
         // issue ahead of the other resident wavefronts
         if (b < p.boost_units) __builtin_amdgcn_s_setprio(3);
+        if (b < p.debug_skip_units) return; // diagnostics only: drop the most expensive packets to see what bounds the frame
     } else {
         const uint32_t xcd = b & 7u, seq = b >> 3, i = seq >> 2;
         const uint32_t kGroup = p.xcd_group;
