@@ -24,6 +24,9 @@ NODE_DTYPE = np.dtype([("lx0", "f4"), ("lx1", "f4"), ("ly0", "f4"), ("ly1", "f4"
                        ("rx0", "f4"), ("rx1", "f4"), ("ry0", "f4"), ("ry1", "f4"),
                        ("lz0", "f4"), ("lz1", "f4"), ("rz0", "f4"), ("rz1", "f4"),
                        ("left", "i4"), ("right", "i4"), ("pad0", "i4"), ("pad1", "i4")])
+NODE4_DTYPE = np.dtype([("minx", "f4", 4), ("maxx", "f4", 4), ("miny", "f4", 4), ("maxy", "f4", 4), ("minz", "f4", 4), ("maxz", "f4", 4),
+                        ("ref", "i4", 4), ("pad", "i4", 4)])
+BVH_EMPTY = -0x80000000
 TRI_DTYPE = np.dtype([("v0", "f4", 3), ("inst", "u4"), ("e1", "f4", 3), ("prim", "u4"),
                       ("e2", "f4", 3), ("gid", "u4")])
 SHADE_DTYPE = np.dtype([("n0", "f4", 3), ("n1", "f4", 3), ("n2", "f4", 3), ("material", "u4"), ("pad", "u4", 2)])
@@ -33,7 +36,7 @@ ABI_SYMBOLS = [
     "crt_abi_version", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
     "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_set_option", "crt_debug_read_timeline", "crt_render_frame", "crt_render_frame_device",
     "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_untile_device", "crt_set_stream", "crt_reset_stream",
-    "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free",
+    "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_build_host4",
     "crt_scene_load", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
     "crt_scene_add_material", "crt_scene_mesh_count", "crt_scene_mesh", "crt_scene_light_count", "crt_scene_light",
     "crt_scene_material_count", "crt_scene_material", "crt_scene_texture_count", "crt_scene_settings",
@@ -123,6 +126,9 @@ def lib():
         "crt_bvh_build_host": (C.c_int, [vp, u32, C.POINTER(vp), C.POINTER(u32), C.POINTER(vp), C.POINTER(vp),
                                          C.POINTER(u32), C.POINTER(u32)]),
         "crt_free": (None, [vp]),
+        "crt_bvh_info4": (C.c_int, [vp, C.POINTER(u32), C.POINTER(u32)]),
+        "crt_bvh_export4": (C.c_int, [vp, vp]),
+        "crt_bvh_build_host4": (C.c_int, [vp, u32, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]),
         "crt_scene_load": (C.c_int, [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]),
         "crt_scene_new": (C.c_int, [C.POINTER(vp)]),
         "crt_scene_free": (None, [vp]),
@@ -386,6 +392,21 @@ def build_bvh_host(meshes):
     return take(pn, nn.value, NODE_DTYPE), take(pt, nt.value, TRI_DTYPE), take(ps, nt.value, SHADE_DTYPE), md.value
 
 
+def build_bvh4_host(meshes):
+    """crt_bvh_build_host4: binary build + collapse to the 4-wide tree the kernels traverse. Returns nodes4, depth4."""
+    L = lib()
+    keep = []
+    mv = _mesh_views(meshes, keep)
+    pn, nn, d4 = C.c_void_p(), C.c_uint32(), C.c_uint32()
+    rc = L.crt_bvh_build_host4(mv, len(meshes), C.byref(pn), C.byref(nn), C.byref(d4))
+    if rc:
+        raise CrtError("crt_bvh_build_host4 rc=%d: %s" % (rc, L.crt_last_error(None).decode()))
+    out = np.zeros(0, dtype=NODE4_DTYPE) if nn.value == 0 else \
+        np.frombuffer((C.c_char * (nn.value * 128)).from_address(pn.value), dtype=NODE4_DTYPE).copy()
+    L.crt_free(pn)
+    return out, d4.value
+
+
 class Renderer:
     """crt_ctx handle: the DXRTRenderer surface over HIP. Raises CrtError when no MI355X / HIP device is usable."""
 
@@ -485,6 +506,13 @@ class Renderer:
         shade = np.zeros(info["n_tris"], dtype=SHADE_DTYPE)
         self._ok(lib().crt_bvh_export(self.h, nodes.ctypes.data, tris.ctypes.data, shade.ctypes.data), "crt_bvh_export")
         return nodes, tris, shade
+
+    def bvh_export4(self):
+        a, b = C.c_uint32(), C.c_uint32()
+        self._ok(lib().crt_bvh_info4(self.h, C.byref(a), C.byref(b)), "crt_bvh_info4")
+        nodes4 = np.zeros(a.value, dtype=NODE4_DTYPE)
+        self._ok(lib().crt_bvh_export4(self.h, nodes4.ctypes.data), "crt_bvh_export4")
+        return nodes4, b.value
 
     def render_frame(self, w, h, want=("rgba8", "hit_inst", "hit_prim", "hit_t", "rgb")):
         """renderFrame with host outputs. Returns dict of arrays + 'stats'."""

@@ -184,6 +184,8 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
     const uint32_t n = static_cast<uint32_t>(total);
 
     out.nodes.clear();
+    out.nodes4.clear();
+    out.depth4 = 0;
     out.tris.clear();
     out.shade.clear();
     out.maxDepth = 0;
@@ -281,6 +283,72 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
     for (uint32_t i = 0; i < n; i++) {
         out.tris[i] = inTri[order[i]];
         out.shade[i] = inShade[order[i]];
+    }
+    collapseBvh4(out);
+}
+
+// Binary -> 4-wide collapse.  A wide node takes the two children of a binary node and, while it has fewer than four
+// slots, replaces the inner slot of largest half-area (first on ties) by that node's two children, in place (left keeps
+// the position, right goes right after it).  Wide nodes are numbered in DFS pre-order, children in slot order.
+// Iterative formulation (explicit work stack, pre-order ids patched into the parent when a child is emitted).
+void collapseBvh4(Bvh& bvh)
+{
+    bvh.nodes4.clear();
+    bvh.depth4 = 0;
+    if (bvh.nodes.empty()) return;
+    struct Slot { int32_t ref; Box box; };
+    auto slotsOf = [&](int32_t b, Slot& l, Slot& r) {
+        const crt_bvh_node& N = bvh.nodes[b];
+        l.ref = N.left;
+        r.ref = N.right;
+        l.box.mn[0] = N.lx0; l.box.mx[0] = N.lx1; l.box.mn[1] = N.ly0; l.box.mx[1] = N.ly1; l.box.mn[2] = N.lz0; l.box.mx[2] = N.lz1;
+        r.box.mn[0] = N.rx0; r.box.mx[0] = N.rx1; r.box.mn[1] = N.ry0; r.box.mx[1] = N.ry1; r.box.mn[2] = N.rz0; r.box.mx[2] = N.rz1;
+    };
+    struct Work { int32_t binary; int32_t parent; int slot; uint32_t depth; }; // parent wide node / slot to patch
+    std::vector<Work> work;
+    work.push_back({ 0, -1, 0, 1 });
+    bvh.nodes4.reserve(bvh.nodes.size() / 2 + 1);
+    while (!work.empty()) {
+        const Work w = work.back();
+        work.pop_back();
+        Slot sl[4];
+        int n = 2;
+        slotsOf(w.binary, sl[0], sl[1]);
+        while (n < 4) {
+            int best = -1;
+            float bestArea = -1.0f;
+            for (int i = 0; i < n; i++) {
+                if (sl[i].ref < 0) continue;
+                const float a = sl[i].box.halfArea();
+                if (a > bestArea) { bestArea = a; best = i; }
+            }
+            if (best < 0) break;
+            Slot l, r;
+            slotsOf(sl[best].ref, l, r);
+            for (int i = n; i > best + 1; i--) sl[i] = sl[i - 1];
+            sl[best] = l;
+            sl[best + 1] = r;
+            n++;
+        }
+        const int32_t me = static_cast<int32_t>(bvh.nodes4.size());
+        bvh.nodes4.emplace_back();
+        crt_bvh_node4& W = bvh.nodes4.back();
+        std::memset(&W, 0, sizeof(W));
+        for (int i = 0; i < 4; i++) {
+            if (i < n) {
+                W.minx[i] = sl[i].box.mn[0]; W.maxx[i] = sl[i].box.mx[0];
+                W.miny[i] = sl[i].box.mn[1]; W.maxy[i] = sl[i].box.mx[1];
+                W.minz[i] = sl[i].box.mn[2]; W.maxz[i] = sl[i].box.mx[2];
+                W.ref[i] = sl[i].ref; // leaf reference, or a binary index patched below when the child is emitted
+            } else {
+                W.ref[i] = CRT_BVH_EMPTY;
+            }
+        }
+        if (w.parent >= 0) bvh.nodes4[w.parent].ref[w.slot] = me;
+        if (w.depth > bvh.depth4) bvh.depth4 = w.depth;
+        // children must come out in slot order right after this node (pre-order): push them in reverse
+        for (int i = n - 1; i >= 0; i--)
+            if (sl[i].ref >= 0) work.push_back({ sl[i].ref, me, i, w.depth + 1 });
     }
 }
 

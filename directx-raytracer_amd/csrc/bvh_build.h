@@ -16,7 +16,9 @@ constexpr int kBins = 16;
 constexpr float kTravCost = 1.0f; // SAH cost of an inner-node visit, in triangle tests
 
 struct Bvh {
-    std::vector<crt_bvh_node> nodes;   // 64 B each, DFS pre-order, node 0 = root
+    std::vector<crt_bvh_node> nodes;   // binary tree, 64 B each, DFS pre-order, node 0 = root (builder output, host only)
+    std::vector<crt_bvh_node4> nodes4; // wide tree collapsed from it, 128 B each, DFS pre-order: what is uploaded and traversed
+    uint32_t depth4 = 0;               // levels of the wide tree
     std::vector<crt_bvh_tri> tris;     // 48 B each, leaf order
     std::vector<crt_bvh_shade> shade;  // 48 B each, leaf order
     uint32_t maxDepth = 0;
@@ -24,5 +26,7 @@ struct Bvh {
 
 // meshes in InstanceID order; triangle gid = running ordinal over meshes. Throws std::runtime_error on bad input.
 void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out);
+// binary -> wide collapse (DESIGN.md "BVH4"); called by buildBvh
+void collapseBvh4(Bvh& bvh);
 
 } // namespace crt

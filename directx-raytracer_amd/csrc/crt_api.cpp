@@ -128,7 +128,7 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.shade = c->dShade;
     p.lights = c->dLights;
     p.mats = c->dMats;
-    p.n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
+    p.n_nodes = static_cast<uint32_t>(c->bvh.nodes4.size());
     p.n_tris = static_cast<uint32_t>(c->bvh.tris.size());
     p.n_lights = c->nLights;
     p.n_mats = c->nMats;
@@ -179,7 +179,10 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         p.timeline = c->dTimeline;
     }
     {
-        const size_t need = static_cast<size_t>(crt::renderUnitCount(p)) * 64u * crt::kStackEntries * sizeof(int);
+        // deepest stack a ray can build: three pending siblings per wide level; what does not fit the LDS part spills
+        const uint32_t deepest = 3u * c->bvh.depth4 + 1u;
+        p.spill_stride = deepest > p.stack_entries ? deepest - p.stack_entries : 1u;
+        const size_t need = static_cast<size_t>(crt::renderUnitCount(p)) * 64u * p.spill_stride * sizeof(int);
         if (c->spillBytes < need) {
             HIP_TRY(c, hipStreamSynchronize(c->stream));
             if (c->dSpill) (void)hipFree(c->dSpill);
@@ -374,16 +377,16 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     freeScene(c);
-    const size_t nb = sizeof(crt_bvh_node) * c->bvh.nodes.size();
+    const size_t nb = sizeof(crt_bvh_node4) * c->bvh.nodes4.size(); // the wide tree is what the kernels traverse
     const size_t tb = sizeof(crt_bvh_tri) * c->bvh.tris.size();
     const size_t sb = sizeof(crt_bvh_shade) * c->bvh.shade.size();
     // +64 bytes of slack so that a speculative wide load of the last record stays inside the allocation
-    HIP_TRY(c, hipMalloc(&c->dNodes, nb + 64));
+    HIP_TRY(c, hipMalloc(&c->dNodes, nb + 128));
     HIP_TRY(c, hipMalloc(&c->dTris, tb + 64));
     HIP_TRY(c, hipMalloc(&c->dShade, sb + 64));
     HIP_TRY(c, hipMalloc(&c->dLights, sizeof(crt_light) * (n_lights + 1)));
     HIP_TRY(c, hipMalloc(&c->dMats, sizeof(crt_material) * (n_materials + 1)));
-    if (nb) HIP_TRY(c, hipMemcpy(c->dNodes, c->bvh.nodes.data(), nb, hipMemcpyHostToDevice));
+    if (nb) HIP_TRY(c, hipMemcpy(c->dNodes, c->bvh.nodes4.data(), nb, hipMemcpyHostToDevice));
     if (tb) HIP_TRY(c, hipMemcpy(c->dTris, c->bvh.tris.data(), tb, hipMemcpyHostToDevice));
     if (sb) HIP_TRY(c, hipMemcpy(c->dShade, c->bvh.shade.data(), sb, hipMemcpyHostToDevice));
     if (n_lights) HIP_TRY(c, hipMemcpy(c->dLights, lights, sizeof(crt_light) * n_lights, hipMemcpyHostToDevice));
@@ -595,6 +598,38 @@ int crt_bvh_info(const crt_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t
     if (n_nodes) *n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
     if (n_tris) *n_tris = static_cast<uint32_t>(c->bvh.tris.size());
     if (max_depth) *max_depth = c->bvh.maxDepth;
+    return CRT_OK;
+}
+
+int crt_bvh_info4(const crt_ctx* c, uint32_t* n_nodes4, uint32_t* depth4)
+{
+    if (!c || !c->haveScene) return CRT_ESTATE;
+    if (n_nodes4) *n_nodes4 = static_cast<uint32_t>(c->bvh.nodes4.size());
+    if (depth4) *depth4 = c->bvh.depth4;
+    return CRT_OK;
+}
+
+int crt_bvh_export4(const crt_ctx* c, crt_bvh_node4* nodes4)
+{
+    if (!c || !c->haveScene) return CRT_ESTATE;
+    if (nodes4) std::memcpy(nodes4, c->bvh.nodes4.data(), sizeof(crt_bvh_node4) * c->bvh.nodes4.size());
+    return CRT_OK;
+}
+
+int crt_bvh_build_host4(const crt_mesh_view* meshes, uint32_t n_meshes, crt_bvh_node4** nodes4, uint32_t* n_nodes4, uint32_t* depth4)
+{
+    if ((!meshes && n_meshes) || !nodes4 || !n_nodes4) return fail(nullptr, CRT_EINVAL, "crt_bvh_build_host4: NULL argument");
+    try {
+        crt::Bvh b;
+        crt::buildBvh(meshes, n_meshes, b);
+        *n_nodes4 = static_cast<uint32_t>(b.nodes4.size());
+        if (depth4) *depth4 = b.depth4;
+        *nodes4 = static_cast<crt_bvh_node4*>(std::malloc(sizeof(crt_bvh_node4) * (b.nodes4.size() + 1)));
+        if (!*nodes4) return fail(nullptr, CRT_ENOMEM, "out of host memory");
+        std::memcpy(*nodes4, b.nodes4.data(), sizeof(crt_bvh_node4) * b.nodes4.size());
+    } catch (const std::exception& ex) {
+        return fail(nullptr, CRT_EINVAL, "BVH build failed: %s", ex.what());
+    }
     return CRT_OK;
 }
 

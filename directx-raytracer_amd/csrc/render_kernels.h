@@ -12,7 +12,7 @@ constexpr int kStackEntries = 32;  // upper bound of the per-lane LDS traversal 
 
 struct RenderParams {
     // scene (HBM)
-    const void* nodes;   // crt_bvh_node[n_nodes], 64 B, 64-B aligned
+    const void* nodes;   // crt_bvh_node4[n_nodes], 128 B (the wide tree)
     const void* tris;    // crt_bvh_tri[n_tris], 48 B
     const void* shade;   // crt_bvh_shade[n_tris], 48 B
     const void* lights;  // crt_light[n_lights]
@@ -42,7 +42,8 @@ struct RenderParams {
     float* hit_t;
     float* rgb_f32;
     unsigned long long* counters; // [0] nodes fetched, [1] triangles fetched, [2] shadow rays, [3] closest-hit rays; counting variant
-    int* spill;                   // stack spill arena: renderUnitCount() x 64 lanes x kStackEntries ints, rarely touched
+    int* spill;                   // stack spill arena: renderUnitCount() x 64 lanes x spill_stride ints, rarely touched
+    uint32_t spill_stride;        // >= 3 * wide depth + 1 - stack_entries: the deepest stack any ray can build
     const uint32_t* unit_order;   // nullable: work units sorted by descending cost of the previous frame (launch order)
     uint32_t* unit_cost;          // nullable: per work unit, traversal-loop iterations of its wavefront (this frame)
     unsigned long long* timeline; // counting variant only, nullable: per workgroup {start, end} of s_memrealtime (100 MHz) + XCC id

@@ -71,6 +71,14 @@ typedef struct crt_bvh_node {
     int32_t left, right; /* >= 0 inner node index; < 0 leaf: ~ref = (first_tri << 3) | count */
     int32_t pad0, pad1;
 } crt_bvh_node;
+/* 128-byte wide node the kernels traverse: up to 4 children, planes stored per axis across the children; collapsed from
+ * the binary tree above. ref >= 0: wide node index; CRT_BVH_EMPTY: unused slot; other negatives: leaf (as above) */
+#define CRT_BVH_EMPTY ((int32_t)0x80000000)
+typedef struct crt_bvh_node4 {
+    float minx[4], maxx[4], miny[4], maxy[4], minz[4], maxz[4];
+    int32_t ref[4];
+    int32_t pad[4];
+} crt_bvh_node4;
 typedef struct crt_bvh_tri { float v0[3]; uint32_t inst; float e1[3]; uint32_t prim; float e2[3]; uint32_t gid; } crt_bvh_tri;
 typedef struct crt_bvh_shade { float n0[3], n1[3], n2[3]; uint32_t material; uint32_t pad[2]; } crt_bvh_shade;
 
@@ -79,7 +87,7 @@ typedef struct crt_frame_stats {
     double total_ms;         /* wall time of the call (includes D2H copies when host outputs are requested) */
     uint64_t rays_primary;   /* closest-hit rays: pixels rendered by this call (x spp + bounce rays in mode 200, exact when counting) */
     uint64_t rays_shadow;    /* counted only when counting is enabled, else 0 */
-    uint64_t nodes_visited;  /* idem: 64-byte node records fetched, summed over all rays */
+    uint64_t nodes_visited;  /* idem: 128-byte wide-node records fetched, summed over all rays */
     uint64_t tris_tested;    /* idem: 48-byte triangle records fetched */
 } crt_frame_stats;
 
@@ -157,10 +165,15 @@ int crt_synchronize(crt_ctx* ctx);
 /* BVH introspection (tests, tooling): sizes, then copies of the host-side arrays uploaded to HBM */
 int crt_bvh_info(const crt_ctx* ctx, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* max_depth);
 int crt_bvh_export(const crt_ctx* ctx, crt_bvh_node* nodes, crt_bvh_tri* tris, crt_bvh_shade* shade);
+/* the wide tree as it sits in HBM: count/depth (any pointer may be NULL), then a copy of the nodes */
+int crt_bvh_info4(const crt_ctx* ctx, uint32_t* n_nodes4, uint32_t* depth4);
+int crt_bvh_export4(const crt_ctx* ctx, crt_bvh_node4* nodes4);
 /* host-only BVH build, no device needed (used by crt_upload_scene; exposed for tests and tooling) */
 int crt_bvh_build_host(const crt_mesh_view* meshes, uint32_t n_meshes,
                        crt_bvh_node** nodes, uint32_t* n_nodes,
                        crt_bvh_tri** tris, crt_bvh_shade** shade, uint32_t* n_tris, uint32_t* max_depth);
+/* same build, additionally returning the collapsed wide tree (nodes4 freed with crt_free) */
+int crt_bvh_build_host4(const crt_mesh_view* meshes, uint32_t n_meshes, crt_bvh_node4** nodes4, uint32_t* n_nodes4, uint32_t* depth4);
 void crt_free(void* p);
 
 /* ---------------------------------------------------------------------------------------------------

@@ -106,8 +106,12 @@ uint8_t oracle_unorm8(float c)
  * scene
  * ---------------------------------------------------------------------------------------------- */
 struct oracle_scene {
-    oracle_node* nodes;
+    oracle_node* nodes;   /* binary tree (the builder's output) */
     uint32_t n_nodes;
+    oracle_node4* nodes4; /* wide tree collapsed from it (what the render loop walks) */
+    uint32_t n_nodes4;
+    uint32_t depth4;
+    int width;
     oracle_tri* tris;     /* leaf order */
     oracle_shade* shade;  /* leaf order */
     uint32_t n_tris;
@@ -247,6 +251,76 @@ static int32_t build_range(builder* B, uint32_t first, uint32_t count, uint32_t 
     return (int32_t)me;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * BVH4: collapse of the binary tree.  A wide node starts with the two children of a binary node; while it has fewer than
+ * four slots, the inner slot with the largest half-area (first one on ties) is replaced in place by its two children
+ * (left at its position, right right after it).  Wide nodes are numbered in DFS pre-order, children in slot order.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { int32_t ref; aabb box; } slot4;
+
+static void child_slots(const oracle_node* N, slot4* l, slot4* r)
+{
+    l->ref = N->left; r->ref = N->right;
+    l->box.mn[0] = N->lx0; l->box.mx[0] = N->lx1; l->box.mn[1] = N->ly0; l->box.mx[1] = N->ly1; l->box.mn[2] = N->lz0; l->box.mx[2] = N->lz1;
+    r->box.mn[0] = N->rx0; r->box.mx[0] = N->rx1; r->box.mn[1] = N->ry0; r->box.mx[1] = N->ry1; r->box.mn[2] = N->rz0; r->box.mx[2] = N->rz1;
+}
+
+typedef struct { const oracle_node* bin; oracle_node4* wide; uint32_t n_wide; uint32_t depth; } collapser;
+
+static int32_t collapse_node(collapser* C, int32_t b, uint32_t depth)
+{
+    slot4 sl[4];
+    int n = 2;
+    child_slots(&C->bin[b], &sl[0], &sl[1]);
+    while (n < 4) {
+        int best = -1;
+        float best_area = -1.0f;
+        for (int i = 0; i < n; i++)
+            if (sl[i].ref >= 0) {
+                float a = aabb_half_area(&sl[i].box);
+                if (a > best_area) { best_area = a; best = i; }
+            }
+        if (best < 0) break;
+        slot4 l, r;
+        child_slots(&C->bin[sl[best].ref], &l, &r);
+        for (int i = n; i > best + 1; i--) sl[i] = sl[i - 1];
+        sl[best] = l;
+        sl[best + 1] = r;
+        n++;
+    }
+    const uint32_t me = C->n_wide++;
+    if (depth + 1 > C->depth) C->depth = depth + 1;
+    oracle_node4 W;
+    memset(&W, 0, sizeof(W));
+    for (int i = 0; i < 4; i++) {
+        if (i < n) {
+            W.minx[i] = sl[i].box.mn[0]; W.maxx[i] = sl[i].box.mx[0];
+            W.miny[i] = sl[i].box.mn[1]; W.maxy[i] = sl[i].box.mx[1];
+            W.minz[i] = sl[i].box.mn[2]; W.maxz[i] = sl[i].box.mx[2];
+            W.ref[i] = sl[i].ref; /* binary index for now */
+        } else {
+            W.ref[i] = ORACLE_EMPTY;
+        }
+    }
+    C->wide[me] = W;
+    for (int i = 0; i < n; i++)
+        if (sl[i].ref >= 0) C->wide[me].ref[i] = collapse_node(C, sl[i].ref, depth + 1);
+    return (int32_t)me;
+}
+
+static void build_wide(oracle_scene* s)
+{
+    free(s->nodes4);
+    s->nodes4 = (oracle_node4*)calloc(s->n_nodes ? s->n_nodes : 1, sizeof(oracle_node4));
+    s->n_nodes4 = 0;
+    s->depth4 = 0;
+    if (s->n_nodes == 0) return;
+    collapser C = { s->nodes, s->nodes4, 0, 0 };
+    collapse_node(&C, 0, 0);
+    s->n_nodes4 = C.n_wide;
+    s->depth4 = C.depth;
+}
+
 oracle_scene* oracle_scene_create(const oracle_mesh* meshes, uint32_t n_meshes,
                                   const oracle_light* lights, uint32_t n_lights,
                                   const oracle_material* mats, uint32_t n_mats)
@@ -323,6 +397,8 @@ oracle_scene* oracle_scene_create(const oracle_mesh* meshes, uint32_t n_meshes,
     s->nodes = B.nodes;
     s->n_nodes = B.n_nodes;
     s->max_depth = B.max_depth;
+    s->width = 4;
+    build_wide(s);
     s->tris = (oracle_tri*)malloc(sizeof(oracle_tri) * (n ? n : 1));
     s->shade = (oracle_shade*)malloc(sizeof(oracle_shade) * (n ? n : 1));
     for (uint32_t i = 0; i < n; i++) { s->tris[i] = in_tri[B.order[i]]; s->shade[i] = in_sh[B.order[i]]; }
@@ -333,7 +409,7 @@ oracle_scene* oracle_scene_create(const oracle_mesh* meshes, uint32_t n_meshes,
 void oracle_scene_destroy(oracle_scene* s)
 {
     if (!s) return;
-    free(s->nodes); free(s->tris); free(s->shade); free(s->lights); free(s->mats);
+    free(s->nodes); free(s->nodes4); free(s->tris); free(s->shade); free(s->lights); free(s->mats);
     free(s);
 }
 
@@ -349,10 +425,15 @@ int oracle_scene_set_bvh(oracle_scene* s, const oracle_node* nodes, uint32_t n_n
     memcpy(s->tris, tris, sizeof(oracle_tri) * n_tris);
     if (shade) memcpy(s->shade, shade, sizeof(oracle_shade) * n_tris);
     s->n_nodes = n_nodes; s->n_tris = n_tris;
+    build_wide(s);
     return 0;
 }
 
 uint32_t oracle_scene_node_count(const oracle_scene* s) { return s->n_nodes; }
+uint32_t oracle_scene_node4_count(const oracle_scene* s) { return s->n_nodes4; }
+const oracle_node4* oracle_scene_nodes4(const oracle_scene* s) { return s->nodes4; }
+uint32_t oracle_scene_depth4(const oracle_scene* s) { return s->depth4; }
+void oracle_scene_set_width(oracle_scene* s, int width) { s->width = width == 2 ? 2 : 4; }
 uint32_t oracle_scene_tri_count(const oracle_scene* s) { return s->n_tris; }
 const oracle_node* oracle_scene_nodes(const oracle_scene* s) { return s->nodes; }
 const oracle_tri* oracle_scene_tris(const oracle_scene* s) { return s->tris; }
@@ -419,7 +500,7 @@ static inline int box_test(float x0, float x1, float y0, float y1, float z0, flo
  * Boxes are culled against tcull = best_t * CULL_PAD, not best_t: the slab distances and the Moeller-Trumbore t
  * round differently, and without the pad a box holding an equal-t (or one-ulp-closer) triangle on a shared edge
  * can be culled, making the winner depend on traversal order. tcull changes only when a hit is accepted. */
-static void trace_closest(const oracle_scene* s, const ray* r, float tmin, float tmax, hit_rec* h, trav_count* c)
+static void trace_closest2(const oracle_scene* s, const ray* r, float tmin, float tmax, hit_rec* h, trav_count* c)
 {
     h->t = tmax; h->u = 0.0f; h->v = 0.0f; h->tri = 0; h->gid = 0; h->hit = 0;
     if (s->n_nodes == 0) return;
@@ -464,7 +545,7 @@ static void trace_closest(const oracle_scene* s, const ray* r, float tmin, float
 }
 
 /* any hit in (tmin, tmax): order independent */
-static int trace_any(const oracle_scene* s, const ray* r, float tmin, float tmax, trav_count* c)
+static int trace_any2(const oracle_scene* s, const ray* r, float tmin, float tmax, trav_count* c)
 {
     if (s->n_nodes == 0) return 0;
     int32_t stack[MAX_DEPTH + 1];
@@ -500,6 +581,123 @@ static int trace_any(const oracle_scene* s, const ray* r, float tmin, float tmax
         cur = stack[--sp];
     }
     return 0;
+}
+
+/* ---- wide (BVH4) traversal: what the HIP kernels do.  Per step: four slab tests; hit children are ordered by the key
+ * (bits(t_near) & 0x7FFFFFFC) | slot (t_near >= 0, so its bit pattern orders like the float; the two low bits carry the
+ * slot and make keys unique); nearest becomes current, the others are pushed farthest first. */
+#define STACK4 (3 * 32 + 4)
+
+static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+
+static inline int wide_step(const oracle_node4* N, const ray* r, float tmin, float tcull, uint32_t key[4])
+{
+    int n_hit = 0;
+    for (int k = 0; k < 4; k++) {
+        float tn;
+        int hit = box_test(N->minx[k], N->maxx[k], N->miny[k], N->maxy[k], N->minz[k], N->maxz[k], r, tmin, tcull, &tn);
+        hit &= N->ref[k] != ORACLE_EMPTY;
+        key[k] = hit ? ((f2u(tn) & 0x7FFFFFFCu) | (uint32_t)k) : 0xFFFFFFFFu;
+        n_hit += hit;
+    }
+    /* sorting network (0,1)(2,3)(0,2)(1,3)(1,2), ascending */
+#define CSWAP(a, b) { uint32_t lo = key[a] < key[b] ? key[a] : key[b]; uint32_t hi = key[a] < key[b] ? key[b] : key[a]; key[a] = lo; key[b] = hi; }
+    CSWAP(0, 1) CSWAP(2, 3) CSWAP(0, 2) CSWAP(1, 3) CSWAP(1, 2)
+#undef CSWAP
+    return n_hit;
+}
+
+static void trace_closest4(const oracle_scene* s, const ray* r, float tmin, float tmax, hit_rec* h, trav_count* c)
+{
+    h->t = tmax; h->u = 0.0f; h->v = 0.0f; h->tri = 0; h->gid = 0; h->hit = 0;
+    if (s->n_nodes4 == 0) return;
+    int32_t stack[STACK4];
+    int sp = 0;
+    int32_t cur = 0;
+    float tcull = tmax * CULL_PAD;
+    for (;;) {
+        if (cur >= 0) {
+            const oracle_node4* N = &s->nodes4[cur];
+            uint32_t key[4];
+            c->nodes++;
+            int n_hit = wide_step(N, r, tmin, tcull, key);
+            if (n_hit > 0) {
+                for (int k = n_hit - 1; k >= 1; k--) stack[sp++] = N->ref[key[k] & 3u];
+                if (sp > t_max_sp) t_max_sp = sp;
+                cur = N->ref[key[0] & 3u];
+                continue;
+            }
+        } else {
+            uint32_t code = (uint32_t)~cur;
+            uint32_t first = code >> 3, cnt = code & 7u;
+            for (uint32_t i = first; i < first + cnt; i++) {
+                const oracle_tri* T = &s->tris[i];
+                float t, u, v;
+                c->tris++;
+                if (tri_test(r, T, tmin, &t, &u, &v)) {
+                    if ((t < h->t) | ((t == h->t) & (T->gid < h->gid))) {
+                        h->t = t; h->u = u; h->v = v; h->tri = i; h->gid = T->gid; h->hit = 1;
+                        tcull = t * CULL_PAD;
+                    }
+                }
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+}
+
+/* any hit: order independent, children taken in slot order (first hit slot next, the others pushed last slot first) */
+static int trace_any4(const oracle_scene* s, const ray* r, float tmin, float tmax, trav_count* c)
+{
+    if (s->n_nodes4 == 0) return 0;
+    int32_t stack[STACK4];
+    int sp = 0;
+    int32_t cur = 0;
+    const float tcull = tmax * CULL_PAD;
+    for (;;) {
+        if (cur >= 0) {
+            const oracle_node4* N = &s->nodes4[cur];
+            c->nodes++;
+            int first_hit = -1;
+            int hits[4];
+            for (int k = 0; k < 4; k++) {
+                float tn;
+                hits[k] = box_test(N->minx[k], N->maxx[k], N->miny[k], N->maxy[k], N->minz[k], N->maxz[k], r, tmin, tcull, &tn) &
+                          (N->ref[k] != ORACLE_EMPTY);
+                if (hits[k] && first_hit < 0) first_hit = k;
+            }
+            if (first_hit >= 0) {
+                for (int k = 3; k > first_hit; k--)
+                    if (hits[k]) stack[sp++] = N->ref[k];
+                if (sp > t_max_sp) t_max_sp = sp;
+                cur = N->ref[first_hit];
+                continue;
+            }
+        } else {
+            uint32_t code = (uint32_t)~cur;
+            uint32_t first = code >> 3, cnt = code & 7u;
+            for (uint32_t i = first; i < first + cnt; i++) {
+                float t, u, v;
+                c->tris++;
+                if (tri_test(r, &s->tris[i], tmin, &t, &u, &v) & (t < tmax)) return 1;
+            }
+        }
+        if (sp == 0) break;
+        cur = stack[--sp];
+    }
+    return 0;
+}
+
+static void trace_closest(const oracle_scene* s, const ray* r, float tmin, float tmax, hit_rec* h, trav_count* c)
+{
+    if (s->width == 2) trace_closest2(s, r, tmin, tmax, h, c);
+    else trace_closest4(s, r, tmin, tmax, h, c);
+}
+
+static int trace_any(const oracle_scene* s, const ray* r, float tmin, float tmax, trav_count* c)
+{
+    return s->width == 2 ? trace_any2(s, r, tmin, tmax, c) : trace_any4(s, r, tmin, tmax, c);
 }
 
 static void brute_closest(const oracle_scene* s, const ray* r, float tmin, float tmax, hit_rec* h, trav_count* c)

@@ -43,6 +43,15 @@ typedef struct oracle_node {
     int32_t pad0, pad1;
 } oracle_node;
 
+/* 128-byte wide node: up to four children, planes stored per axis across the children (SoA). Built by collapsing the
+ * binary tree (DESIGN.md "BVH4"). ref >= 0: wide node index; ORACLE_EMPTY: unused slot; other negatives: leaf as above. */
+#define ORACLE_EMPTY ((int32_t)0x80000000)
+typedef struct oracle_node4 {
+    float minx[4], maxx[4], miny[4], maxy[4], minz[4], maxz[4];
+    int32_t ref[4];
+    int32_t pad[4];
+} oracle_node4;
+
 /* 48-byte leaf-ordered triangle: v0 and the two edges, ids in the w lanes. */
 typedef struct oracle_tri {
     float v0[3]; uint32_t inst; /* mesh ordinal      (DXR InstanceID)     */
@@ -87,6 +96,11 @@ int oracle_scene_set_bvh(oracle_scene* s, const oracle_node* nodes, uint32_t n_n
                          const oracle_tri* tris, const oracle_shade* shade, uint32_t n_tris);
 
 uint32_t oracle_scene_node_count(const oracle_scene* s);
+uint32_t oracle_scene_node4_count(const oracle_scene* s);
+const oracle_node4* oracle_scene_nodes4(const oracle_scene* s);
+uint32_t oracle_scene_depth4(const oracle_scene* s);
+/* traversal width used by oracle_render: 4 (default, the wide tree the kernels walk) or 2 (the binary tree it is collapsed from) */
+void oracle_scene_set_width(oracle_scene* s, int width);
 uint32_t oracle_scene_tri_count(const oracle_scene* s);
 const oracle_node* oracle_scene_nodes(const oracle_scene* s);
 const oracle_tri* oracle_scene_tris(const oracle_scene* s);

@@ -18,10 +18,13 @@ NODE_DTYPE = np.dtype([("lx0", "f4"), ("lx1", "f4"), ("ly0", "f4"), ("ly1", "f4"
                        ("rx0", "f4"), ("rx1", "f4"), ("ry0", "f4"), ("ry1", "f4"),
                        ("lz0", "f4"), ("lz1", "f4"), ("rz0", "f4"), ("rz1", "f4"),
                        ("left", "i4"), ("right", "i4"), ("pad0", "i4"), ("pad1", "i4")])
+NODE4_DTYPE = np.dtype([("minx", "f4", 4), ("maxx", "f4", 4), ("miny", "f4", 4), ("maxy", "f4", 4), ("minz", "f4", 4), ("maxz", "f4", 4),
+                        ("ref", "i4", 4), ("pad", "i4", 4)])
+EMPTY = -0x80000000
 TRI_DTYPE = np.dtype([("v0", "f4", 3), ("inst", "u4"), ("e1", "f4", 3), ("prim", "u4"),
                       ("e2", "f4", 3), ("gid", "u4")])
 SHADE_DTYPE = np.dtype([("n0", "f4", 3), ("n1", "f4", 3), ("n2", "f4", 3), ("material", "u4"), ("pad", "u4", 2)])
-assert NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 48 and SHADE_DTYPE.itemsize == 48
+assert NODE4_DTYPE.itemsize == 128 and NODE_DTYPE.itemsize == 64 and TRI_DTYPE.itemsize == 48 and SHADE_DTYPE.itemsize == 48
 
 
 class _Mesh(C.Structure):
@@ -66,10 +69,11 @@ def lib():
         L.oracle_scene_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
         L.oracle_scene_destroy.argtypes = [C.c_void_p]
         L.oracle_scene_set_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
-        for f in ("oracle_scene_node_count", "oracle_scene_tri_count", "oracle_scene_max_depth"):
+        L.oracle_scene_set_width.argtypes = [C.c_void_p, C.c_int]
+        for f in ("oracle_scene_node_count", "oracle_scene_tri_count", "oracle_scene_max_depth", "oracle_scene_node4_count", "oracle_scene_depth4"):
             getattr(L, f).restype = C.c_uint32
             getattr(L, f).argtypes = [C.c_void_p]
-        for f in ("oracle_scene_nodes", "oracle_scene_tris", "oracle_scene_shade"):
+        for f in ("oracle_scene_nodes", "oracle_scene_tris", "oracle_scene_shade", "oracle_scene_nodes4"):
             getattr(L, f).restype = C.c_void_p
             getattr(L, f).argtypes = [C.c_void_p]
         L.oracle_render.restype = C.c_int
@@ -159,6 +163,21 @@ class OracleScene:
     @property
     def max_depth(self):
         return lib().oracle_scene_max_depth(self.h)
+
+    @property
+    def n_nodes4(self):
+        return lib().oracle_scene_node4_count(self.h)
+
+    @property
+    def depth4(self):
+        return lib().oracle_scene_depth4(self.h)
+
+    def nodes4(self):
+        return self._view("oracle_scene_nodes4", NODE4_DTYPE, self.n_nodes4)
+
+    def set_width(self, width):
+        """4 = wide tree (default, what the kernels walk), 2 = the binary tree it is collapsed from"""
+        lib().oracle_scene_set_width(self.h, int(width))
 
     def _view(self, fn, dtype, n):
         p = getattr(lib(), fn)(self.h)

@@ -53,9 +53,45 @@ def _check_structure(nodes, tris, n_input, max_depth_reported):
     assert sorted(tris["gid"].tolist()) == list(range(n_input))
 
 
+def _check_wide(nodes, nodes4, depth4, tris):
+    """the wide tree is a collapse of the binary one: same leaves, each exactly once, every child box inside the
+    union its binary ancestors gave it, DFS pre-order, at most 4 children, unused slots marked empty"""
+    if len(nodes) == 0:
+        assert len(nodes4) == 0
+        return
+    EMPTY = -0x80000000
+    seen = np.zeros(len(tris), dtype=np.int32)
+    order, stack, deepest = [], [(0, 1)], 0
+    while stack:
+        i, d = stack.pop()
+        order.append(i)
+        deepest = max(deepest, d)
+        n = nodes4[i]
+        refs = [int(r) for r in n["ref"]]
+        used = [r for r in refs if r != EMPTY]
+        assert 2 <= len(used) <= 4 and refs[:len(used)] == used, "empty slots trail"
+        for k in reversed(range(len(used))):
+            r = used[k]
+            assert n["minx"][k] <= n["maxx"][k] and n["miny"][k] <= n["maxy"][k] and n["minz"][k] <= n["maxz"][k]
+            if r >= 0:
+                assert r > i
+                stack.append((r, d + 1))
+            else:
+                code = ~r & 0xFFFFFFFF
+                first, cnt = code >> 3, code & 7
+                seen[first:first + cnt] += 1
+    assert order == list(range(len(nodes4))), "DFS pre-order"
+    assert np.all(seen == 1)
+    assert deepest == depth4 <= 32
+    assert len(nodes4) <= len(nodes)
+
+
 def _compare(pkg, oracle, meshes):
     nodes, tris, shade, md = pkg.build_bvh_host(meshes)
     O = oracle.OracleScene(meshes)
+    nodes4, depth4 = pkg.build_bvh4_host(meshes)
+    assert nodes4.tobytes() == O.nodes4().tobytes() and depth4 == O.depth4
+    _check_wide(nodes, nodes4, depth4, tris)
     assert nodes.tobytes() == O.nodes().tobytes()
     assert tris.tobytes() == O.tris().tobytes()
     assert shade.tobytes() == O.shade().tobytes()

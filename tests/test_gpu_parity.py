@@ -34,6 +34,8 @@ def _compare(pkg, oracle, renderer, sc, w, h, modes, exact_float=True, count=Tru
     # the product's own BVH is what sits in HBM; the oracle built its own independently: they must be identical
     nodes, tris, shade = renderer.bvh_export()
     assert nodes.tobytes() == O.nodes().tobytes() and tris.tobytes() == O.tris().tobytes() and shade.tobytes() == O.shade().tobytes()
+    nodes4, depth4 = renderer.bvh_export4()  # the wide tree actually traversed
+    assert nodes4.tobytes() == O.nodes4().tobytes() and depth4 == O.depth4
     for mode in modes:
         renderer.change_shading_mode(mode)
         renderer.set_counting(count)

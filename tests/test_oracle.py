@@ -332,3 +332,19 @@ def test_rng_known_answers(oracle):
     t_exp = 2.0 * math.sqrt(x * x + y * y + 1)
     assert abs(float(out["hit_t"][0, 0]) - t_exp) < 1e-5
     np.testing.assert_array_equal(out["rgb"][0, 0], np.float32([0.5, 0.25, 0.125]))
+
+
+def test_wide_and_binary_traversal_agree(oracle, scenes, dragon):
+    """The 4-wide tree (what the kernels walk) is a collapse of the binary tree: both traversals must report the same
+    hits, t and colours; the wide one takes about half the node fetches."""
+    for sc, (w, h) in ((scenes.cornell_box(), (128, 128)), (dragon, (320, 180)), (scenes.displaced_sphere(40, 40), (160, 90))):
+        S = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+        cam = sc["camera"]
+        S.set_width(4)
+        a = S.render(cam["position"], cam["matrix"], 100, w, h)
+        S.set_width(2)
+        b = S.render(cam["position"], cam["matrix"], 100, w, h)
+        for k in ("hit_inst", "hit_prim", "hit_t", "rgb", "rgba8"):
+            assert np.array_equal(a[k], b[k]), k
+        assert a["stats"]["rays_shadow"] == b["stats"]["rays_shadow"]
+        assert a["stats"]["nodes_visited"] < 0.75 * b["stats"]["nodes_visited"]
