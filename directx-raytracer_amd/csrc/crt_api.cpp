@@ -49,7 +49,7 @@ struct crt_ctx {
     uint32_t mode = 0;                 // R/DXRTRenderer.h:246 default shading mode
     bool counting = false;
     uint32_t pathSpp = 4, pathBounces = 3, pathSeed = 1234; // mode 200 (BASELINE.json configs[4]: 4 spp, 3 bounces)
-    uint32_t tuneInnerMin = 16;    // wave scheduling threshold of the traversal loop (render_kernels.hip)
+    uint32_t tuneInnerMin = 32;    // wave scheduling threshold of the traversal loop (render_kernels.hip)
     uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
     uint32_t tuneXcdGroup = 16;
     uint32_t tuneBoostUnits = 512;
