@@ -211,7 +211,7 @@ def main():
                     traffic = None
             line["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                                "kernel": "renderKernel<false, 64>", "algorithmic_bytes_per_launch": alg_bytes_frame,
+                                "kernel": "renderKernel<false, false>", "algorithmic_bytes_per_launch": alg_bytes_frame,
                                 "nodes_fetched": cnt["nodes_visited"], "tris_fetched": cnt["tris_tested"],
                                 "kernel_ms_event_median": kernel_ms,
                                 "note": "bytes = 128 B x wide-node records fetched + 48 B x triangle records fetched + 4 B x pixels; "

@@ -38,7 +38,7 @@ def main():
                 meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
         for k, v in acc.items():
             med[k] = {"median": statistics.median(v), "min": min(v), "max": max(v), "launches": len(v)}
-    out = {"kernel": "renderKernel<false, 64>", "dispatch": meta, "counters": med}
+    out = {"kernel": "renderKernel<false, false>", "dispatch": meta, "counters": med}
     if "FETCH_SIZE" in med and "WRITE_SIZE" in med:
         rd = med["FETCH_SIZE"]["median"] * 1024.0 * 2.0   # gfx950 correction, see docstring
         wr = med["WRITE_SIZE"]["median"] * 1024.0
