@@ -70,7 +70,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--scene", default="heightfield", choices=["heightfield", "soup"])
+    ap.add_argument("--scene", default="heightfield", choices=["heightfield", "soup", "heightfield5m"],
+                    help="heightfield = BASELINE.json configs[2] (the headline); heightfield5m = same view over 4 999 124 triangles "
+                         "(working set 650 MB > the 256 MB Infinity Cache: the HBM-regime data point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="rehearse the N>1 code path (RCCL init, tile staging, all-gather, "
                     "de-interleave) with whatever world size the launcher gives, even 1")
@@ -102,7 +104,8 @@ def main():
     scenes = importlib.import_module(entry.PKG_NAME + ".scenes")
     host = importlib.import_module(entry.PKG_NAME + ".multigpu")
 
-    sc = scenes.heightfield(n_lights=1) if args.scene == "heightfield" else scenes.icosphere_soup()
+    sc = {"heightfield": lambda: scenes.heightfield(n_lights=1), "soup": scenes.icosphere_soup,
+          "heightfield5m": lambda: scenes.heightfield(n=1581, n_lights=1)}[args.scene]()
     n_tris = sum(len(m["triangles"]) for m in sc["meshes"])
     cam = sc["camera"]
     r = pkg.Renderer(local_rank)
@@ -188,8 +191,9 @@ def main():
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "%s, %d triangles, %dx%d, 1 spp primary + 1 shadow ray per lit hit (mode 100, %d light)"
-                                   % ("seeded height field 708x708 quads + ground quad (BASELINE.json configs[2])" if args.scene == "heightfield"
-                                      else "seeded soup of 3125 copied icospheres + ground quad", n_tris, W, H, len(sc["lights"])),
+                                   % ({"heightfield": "seeded height field 708x708 quads + ground quad (BASELINE.json configs[2])",
+                                       "heightfield5m": "seeded height field 1581x1581 quads + ground quad",
+                                       "soup": "seeded soup of 3125 copied icospheres + ground quad"}[args.scene], n_tris, W, H, len(sc["lights"])),
                        "rays_per_frame": rays_per_frame, "primary_rays": cnt["rays_primary"], "shadow_rays": cnt["rays_shadow"],
                        "parallelism": "1 GPU, one launch per frame" if world == 1 else "framebuffer tiles 16x16 round-robin over %d GPUs + 1 RCCL all-gather/frame" % world,
                        "bvh": {"nodes": r.bvh_info()["n_nodes"], "max_depth": r.bvh_info()["max_depth"], "build_and_upload_s": upload_s}},

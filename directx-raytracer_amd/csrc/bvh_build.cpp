@@ -54,8 +54,8 @@ struct Builder {
 
     inline int binOf(uint32_t prim, int axis, float lo, float scale) const
     {
-        int b = static_cast<int>((cent[3 * prim + axis] - lo) * scale);
-        return b > kBins - 1 ? kBins - 1 : b;
+        const float f = (cent[3 * prim + axis] - lo) * scale; // NaN (triangle with a NaN vertex) -> bin 0, never out of range
+        return f >= 0.0f ? (f < static_cast<float>(kBins) ? static_cast<int>(f) : kBins - 1) : 0;
     }
 
     int32_t build(uint32_t first, uint32_t count, uint32_t depth, Box& bounds)

@@ -33,6 +33,9 @@ constexpr uint32_t kBoostAfter = 300;
 #ifndef NODE_STEPS
 #define NODE_STEPS 2
 #endif
+#ifndef LEAF_PAIRS
+#define LEAF_PAIRS 1
+#endif
 #ifndef OCTANT_SPECIALISE
 #define OCTANT_SPECIALISE 1
 #endif // traversal-loop iterations after which a wavefront raises its issue priority
@@ -294,6 +297,32 @@ __device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes
         if ((cur < 0) & (cur != kDone)) {
             const uint32_t code = static_cast<uint32_t>(~cur);
             const uint32_t first = code >> 3, cnt = code & 7u;
+#if LEAF_PAIRS
+            // two triangles per memory round trip (same test order): the second record's loads overlap the first's
+            for (uint32_t i = first; i < first + cnt; i += 2) {
+                const bool two = i + 1 < first + cnt;
+                const float4* T = tris + 3 * static_cast<size_t>(i);
+                const float4* T1 = two ? T + 3 : T;
+                const float4 a = T[0], b = T[1], c = T[2];
+                const float4 a1 = T1[0], b1 = T1[1], c1 = T1[2];
+                if (COUNT) cntTris += two ? 2u : 1u;
+                float t, u, v;
+                if (triTest(r, a, b, c, tmin, t, u, v)) {
+                    const uint32_t gid = __float_as_uint(c.w);
+                    if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
+                        h.t = t; h.u = u; h.v = v; h.tri = i; h.gid = gid;
+                        tcull = t * kCullPad;
+                    }
+                }
+                if (two & triTest(r, a1, b1, c1, tmin, t, u, v)) {
+                    const uint32_t gid = __float_as_uint(c1.w);
+                    if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
+                        h.t = t; h.u = u; h.v = v; h.tri = i + 1; h.gid = gid;
+                        tcull = t * kCullPad;
+                    }
+                }
+            }
+#else
             for (uint32_t i = first; i < first + cnt; i++) {
                 const float4* T = tris + 3 * static_cast<size_t>(i);
                 const float4 a = T[0], b = T[1], c = T[2];
@@ -307,6 +336,7 @@ __device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes
                     }
                 }
             }
+#endif
             cur = stack.sp == 0 ? kDone : stack.pop();
         }
     }

@@ -148,6 +148,9 @@ typedef struct {
     uint32_t max_depth;
 } builder;
 
+/* bin of a scaled centroid offset: [0, N_BINS-1]; NaN (a triangle with a NaN vertex) goes to bin 0 instead of UB */
+static inline int bin_of(float f) { return f >= 0.0f ? (f < (float)N_BINS ? (int)f : N_BINS - 1) : 0; }
+
 static inline int32_t leaf_ref(uint32_t first, uint32_t count) { return ~(int32_t)((first << 3) | count); }
 
 /* Deterministic binned-SAH build of order[first, first+count). Returns the child reference and the
@@ -186,8 +189,7 @@ static int32_t build_range(builder* B, uint32_t first, uint32_t count, uint32_t 
         for (int b = 0; b < N_BINS; b++) { aabb_empty(&bbox[b]); bcnt[b] = 0; }
         for (uint32_t i = first; i < first + count; i++) {
             uint32_t p = B->order[i];
-            int b = (int)((B->pcent[3 * p + a] - cbox.mn[a]) * scale);
-            if (b > N_BINS - 1) b = N_BINS - 1;
+            int b = bin_of((B->pcent[3 * p + a] - cbox.mn[a]) * scale);
             bcnt[b]++;
             aabb_grow(&bbox[b], &B->pbox[p]);
         }
@@ -226,8 +228,7 @@ static int32_t build_range(builder* B, uint32_t first, uint32_t count, uint32_t 
         uint32_t nl = 0, nr = 0;
         for (uint32_t i = first; i < first + count; i++) {
             uint32_t p = B->order[i];
-            int b = (int)((B->pcent[3 * p + best_axis] - cbox.mn[best_axis]) * best_scale);
-            if (b > N_BINS - 1) b = N_BINS - 1;
+            int b = bin_of((B->pcent[3 * p + best_axis] - cbox.mn[best_axis]) * best_scale);
             if (b < best_plane) B->order[first + nl++] = p; /* nl <= i - first: never overtakes the read */
             else B->tmp[nr++] = p;
         }

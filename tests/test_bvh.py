@@ -157,3 +157,17 @@ def test_depth_bound_on_adversarial_input(pkg, oracle):
     nodes, tris, shade, md = pkg.build_bvh_host([{"vertices": v, "triangles": t}])
     assert md <= 32
     _compare(pkg, oracle, [{"vertices": v, "triangles": t}])
+
+
+def test_nan_vertices_do_not_break_the_builders(pkg, oracle):
+    """a NaN vertex anywhere in a larger mesh: both builders still agree and nothing indexes out of range"""
+    rng = np.random.default_rng(3)
+    v = rng.uniform(-5, 5, size=(300, 3)).astype(np.float32)
+    t = np.arange(300, dtype=np.uint32).reshape(-1, 3)
+    for poison in (0, 150, 299):
+        w = v.copy()
+        w[poison, poison % 3] = np.nan
+        nodes, tris, shade, md = pkg.build_bvh_host([{"vertices": w, "triangles": t}])
+        O = oracle.OracleScene([{"vertices": w, "triangles": t}])
+        assert nodes.tobytes() == O.nodes().tobytes() and tris.tobytes() == O.tris().tobytes()
+        assert sorted(tris["gid"].tolist()) == list(range(100))

@@ -357,3 +357,41 @@ def test_headless_cpp_driver_matches_binding(pkg, oracle, scenes, dragon, tmp_pa
     # failure is an error message and a non-zero exit code, never an assert/abort
     bad = subprocess.run([exe, str(tmp_path / "nope.crtscene")], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "cannot open" in bad.stderr
+
+
+def test_context_lifecycle_and_reuse(pkg, oracle, scenes, dragon):
+    """re-upload, frame-size changes, two contexts at once, NaN vertices, many small frames: no state leaks between
+    frames/contexts; results stay the oracle's."""
+    sc1, sc2 = scenes.cornell_box(), _with_normals(scenes, dragon)
+    O1 = oracle.OracleScene(sc1["meshes"], sc1["lights"], sc1["materials"])
+    O2 = oracle.OracleScene(sc2["meshes"], sc2["lights"], sc2["materials"])
+    a, b = pkg.Renderer(0), pkg.Renderer(0)
+    try:
+        a.upload(sc1["meshes"], sc1["lights"], sc1["materials"])
+        b.upload(sc2["meshes"], sc2["lights"], sc2["materials"])
+        a.set_camera(sc1["camera"]["position"], sc1["camera"]["matrix"])
+        b.set_camera(sc2["camera"]["position"], sc2["camera"]["matrix"])
+        a.change_shading_mode(100)
+        b.change_shading_mode(2)
+        for (w, h) in ((64, 64), (300, 200), (64, 64), (1920, 1080), (33, 9)):
+            ga, gb = a.render_frame(w, h), b.render_frame(w, h)
+            ra = O1.render(sc1["camera"]["position"], sc1["camera"]["matrix"], 100, w, h)
+            rb = O2.render(sc2["camera"]["position"], sc2["camera"]["matrix"], 2, w, h)
+            assert np.array_equal(ga["rgba8"], ra["rgba8"]) and np.array_equal(gb["rgba8"], rb["rgba8"]), (w, h)
+            assert np.array_equal(ga["hit_prim"], ra["hit_prim"]) and np.array_equal(gb["hit_prim"], rb["hit_prim"])
+        # swap the scenes between the contexts
+        a.upload(sc2["meshes"], sc2["lights"], sc2["materials"])
+        a.set_camera(sc2["camera"]["position"], sc2["camera"]["matrix"])
+        a.change_shading_mode(2)
+        assert np.array_equal(a.render_frame(300, 200)["rgba8"], O2.render(sc2["camera"]["position"], sc2["camera"]["matrix"], 2, 300, 200)["rgba8"])
+        # a mesh with a NaN vertex: the triangle can never be hit (comparisons with NaN fail), nothing crashes
+        v = np.float32([(-1, -1, -3), (1, -1, -3), (0, 1, -3), (np.nan, 0, -2), (1, 0, -2), (0, 1, -2)])
+        weird = {"meshes": [{"vertices": v, "triangles": [(0, 1, 2), (3, 4, 5)]}], "lights": [], "materials": []}
+        a.upload(weird["meshes"])
+        a.set_camera((0, 0, 0), scenes.IDENTITY)
+        a.change_shading_mode(3)
+        out = a.render_frame(64, 64)
+        assert set(np.unique(out["hit_prim"]).tolist()) <= {0, pkg.MISS} and (out["hit_prim"] == 0).any()
+    finally:
+        a.close()
+        b.close()
