@@ -74,6 +74,9 @@ def main():
                     help="heightfield = BASELINE.json configs[2] (the headline); heightfield5m = same view over 4 999 124 triangles "
                          "(working set 650 MB > the 256 MB Infinity Cache: the HBM-regime data point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--inflight", type=int, default=4, help="frames in flight: consecutive frames alternate over this many HIP "
+                    "streams and frame buffers (the reference keeps 2 swap-chain buffers, R/DXRTRenderer.cpp:178-204), so "
+                    "the tail of one frame's long packets overlaps the start of the next; 1 = strictly one frame at a time")
     ap.add_argument("--force-dist", action="store_true", help="rehearse the N>1 code path (RCCL init, tile staging, all-gather, "
                     "de-interleave) with whatever world size the launcher gives, even 1")
     args = ap.parse_args()
@@ -114,10 +117,13 @@ def main():
     upload_s = time.perf_counter() - t0
     r.set_camera(cam["position"], cam["matrix"])
     r.change_shading_mode(MODE)
-    stream = torch.cuda.current_stream()
-    r.set_stream(stream.cuda_stream)  # the kernels run on torch's current stream: torch events and RCCL order with them
+    n_fly = max(1, args.inflight)
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_fly - 1)]
+    stream = streams[0]
+    r.set_stream(stream.cuda_stream)  # the kernels run on torch streams: torch events and RCCL order with them
 
-    frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    frames = [torch.zeros(W * H, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
+    frame = frames[0]
     # instrumented variant, once, untimed: exact ray / node / triangle counts of the whole frame
     r.set_counting(True)
     cnt = r.render_frame_device(W, H, frame.data_ptr(), stats=True)
@@ -126,38 +132,43 @@ def main():
     alg_bytes_frame = 128 * cnt["nodes_visited"] + 48 * cnt["tris_tested"] + 4 * W * H  # 128-B wide nodes, 48-B triangles
 
     if not multi:
-        def step():
-            r.render_frame_device(W, H, frame.data_ptr())
+        def step(i):
+            k = i % n_fly
+            r.set_stream(streams[k].cuda_stream)
+            r.render_frame_device(W, H, frames[k].data_ptr())
     else:
         share = host.rank_share(W, H, rank, world)
-        staging = torch.zeros(share["slots"] * 256, dtype=torch.int32, device="cuda")
-        gathered = torch.zeros(world * share["slots"] * 256, dtype=torch.int32, device="cuda")
+        staging = [torch.zeros(share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
+        gathered = [torch.zeros(world * share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
 
-        def untile(g):
-            r.untile_device(W, H, world, g.data_ptr(), frame.data_ptr())
-            return frame
-
-        def step():
-            r.render_tiles_device(W, H, rank, world, staging.data_ptr())
-            host.gather_frame(staging, W, H, untile, gathered)
+        def step(i):
+            k = i % n_fly
+            r.set_stream(streams[k].cuda_stream)
+            with torch.cuda.stream(streams[k]):
+                r.render_tiles_device(W, H, rank, world, staging[k].data_ptr())
+                host.gather_frame(staging[k], W, H, lambda g, k=k: (r.untile_device(W, H, world, g.data_ptr(), frames[k].data_ptr()), frames[k])[1],
+                                  gathered[k])
 
     def fence():
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
+    for i in range(args.warmup):
+        step(i)
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
+    for st in streams[1:]:
+        stream.wait_stream(st)
     ev1.record(stream)
     fence()
     elapsed = time.perf_counter() - t0
-    stream_ms = ev0.elapsed_time(ev1)  # HIP events on the stream the kernels were launched on
+    stream_ms = ev0.elapsed_time(ev1)  # HIP events over the timed region (stream 0 joins the other streams first)
+    r.set_stream(stream.cuda_stream)
     if multi:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -169,7 +180,7 @@ def main():
         if not multi:
             kms.append(r.render_frame_device(W, H, frame.data_ptr(), stats=True)["kernel_ms"])
         else:
-            kms.append(r.render_tiles_device(W, H, rank, world, staging.data_ptr(), stats=True)["kernel_ms"])
+            kms.append(r.render_tiles_device(W, H, rank, world, staging[0].data_ptr(), stats=True)["kernel_ms"])
     kernel_ms = float(np.median(kms))
 
     # PCIe-inclusive variant (host output buffer handed over the C ABI), for DESIGN.md; never `value`
@@ -195,6 +206,7 @@ def main():
                                        "heightfield5m": "seeded height field 1581x1581 quads + ground quad",
                                        "soup": "seeded soup of 3125 copied icospheres + ground quad"}[args.scene], n_tris, W, H, len(sc["lights"])),
                        "rays_per_frame": rays_per_frame, "primary_rays": cnt["rays_primary"], "shadow_rays": cnt["rays_shadow"],
+                       "frames_in_flight": n_fly,
                        "parallelism": "1 GPU, one launch per frame" if world == 1 else "framebuffer tiles 16x16 round-robin over %d GPUs + 1 RCCL all-gather/frame" % world,
                        "bvh": {"nodes": r.bvh_info()["n_nodes"], "max_depth": r.bvh_info()["max_depth"], "build_and_upload_s": upload_s}},
             "ms_per_frame": ms_per_step,

@@ -34,7 +34,7 @@ SHADE_DTYPE = np.dtype([("n0", "f4", 3), ("n1", "f4", 3), ("n2", "f4", 3), ("mat
 # every symbol include/crt_hip.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
     "crt_abi_version", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
-    "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_set_option", "crt_debug_read_timeline", "crt_render_frame", "crt_render_frame_device",
+    "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_set_option", "crt_debug_read_timeline", "crt_debug_read_counters", "crt_render_frame", "crt_render_frame_device",
     "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_untile_device", "crt_set_stream", "crt_reset_stream",
     "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_build_host4",
     "crt_scene_load", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
@@ -112,6 +112,7 @@ def lib():
         "crt_set_counting": (C.c_int, [vp, C.c_int]),
         "crt_set_option": (C.c_int, [vp, C.c_char_p, C.c_int]),
         "crt_debug_read_timeline": (C.c_int, [vp, vp, C.c_size_t, C.POINTER(C.c_size_t)]),
+        "crt_debug_read_counters": (C.c_int, [vp, vp]),
         "crt_render_frame": (C.c_int, [vp, u32, u32, vp, vp, vp, vp, vp, vp]),
         "crt_render_frame_device": (C.c_int, [vp, u32, u32, vp, vp, vp, vp, vp, vp]),
         "crt_tile_count": (u32, [u32, u32]),
@@ -477,6 +478,11 @@ class Renderer:
 
     def set_option(self, name, value):
         self._ok(lib().crt_set_option(self.h, name.encode(), int(value)), "crt_set_option")
+
+    def read_counters(self):
+        buf = np.zeros(16, dtype=np.uint64)
+        self._ok(lib().crt_debug_read_counters(self.h, buf.ctypes.data), "crt_debug_read_counters")
+        return buf
 
     def read_timeline(self, max_words=1 << 22):
         buf = np.zeros(max_words, dtype=np.uint64)

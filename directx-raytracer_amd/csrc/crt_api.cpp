@@ -64,8 +64,9 @@ struct crt_ctx {
     hipStream_t sideStream = nullptr; // runs the sort of frame k concurrently with the render of frame k+1
     hipEvent_t evRender[2] = { nullptr, nullptr }, evSort[2] = { nullptr, nullptr };
     unsigned long long* dCounters = nullptr;
-    int* dSpill = nullptr; // traversal-stack spill arena (render_kernels.hip Stack)
-    size_t spillBytes = 0;
+    int* dSpill[2] = { nullptr, nullptr }; // traversal-stack spill arenas (render_kernels.hip Stack); two, because two
+    size_t spillBytes[2] = { 0, 0 };       // consecutive frames may run concurrently on alternating streams
+    uint32_t spillTurn = 0;
     unsigned long long* dTimeline = nullptr; // diagnostic: 3 words per workgroup, counting variant only
     size_t timelineWords = 0;
     bool wantTimeline = false;
@@ -166,7 +167,7 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
 int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
 {
     const bool counting = c->counting;
-    if (counting) HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 4 * sizeof(unsigned long long), c->stream));
+    if (counting) HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 16 * sizeof(unsigned long long), c->stream));
     if (c->wantTimeline) {
         const size_t words = 3 * (static_cast<size_t>(p.tiles_x + 4) * (p.tiles_y + 4) * 4 + 1024);
         if (c->timelineWords < words) {
@@ -183,15 +184,16 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         const uint32_t deepest = 3u * c->bvh.depth4 + 1u;
         p.spill_stride = deepest > p.stack_entries ? deepest - p.stack_entries : 1u;
         const size_t need = static_cast<size_t>(crt::renderUnitCount(p)) * 64u * p.spill_stride * sizeof(int);
-        if (c->spillBytes < need) {
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
-            if (c->dSpill) (void)hipFree(c->dSpill);
-            c->dSpill = nullptr;
-            c->spillBytes = 0;
-            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dSpill), need));
-            c->spillBytes = need;
+        const uint32_t turn = c->spillTurn++ & 1u;
+        if (c->spillBytes[turn] < need) {
+            HIP_TRY(c, hipDeviceSynchronize());
+            if (c->dSpill[turn]) (void)hipFree(c->dSpill[turn]);
+            c->dSpill[turn] = nullptr;
+            c->spillBytes[turn] = 0;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dSpill[turn]), need));
+            c->spillBytes[turn] = need;
         }
-        p.spill = c->dSpill;
+        p.spill = c->dSpill[turn];
     }
     // Cost feedback: the lifetimes frame k's wavefronts report are sorted on a side stream WHILE frame k+1 renders and
     // order the launch of frame k+2 (two alternating buffer sets), so the sort never sits on the frame's critical path.
@@ -300,7 +302,7 @@ int crt_create(crt_ctx** out, int device_id)
         (e = hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->evRender[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evRender[1], hipEventDisableTiming)) != hipSuccess ||
         (e = hipEventCreateWithFlags(&c->evSort[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evSort[1], hipEventDisableTiming)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&c->dCounters), 4 * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc(reinterpret_cast<void**>(&c->dCounters), 16 * sizeof(unsigned long long))) != hipSuccess) {
         const int rc = fail(nullptr, CRT_ENODEVICE, "HIP initialisation failed on device %d: %s", device_id, hipGetErrorString(e));
         crt_destroy(c);
         return rc;
@@ -319,7 +321,8 @@ void crt_destroy(crt_ctx* c)
     for (int i = 0; i < 5; i++)
         if (c->dFrame[i]) (void)hipFree(c->dFrame[i]);
     if (c->dCounters) (void)hipFree(c->dCounters);
-    if (c->dSpill) (void)hipFree(c->dSpill);
+    for (int i = 0; i < 2; i++)
+        if (c->dSpill[i]) (void)hipFree(c->dSpill[i]);
     if (c->sideStream) (void)hipStreamSynchronize(c->sideStream);
     for (int i = 0; i < 2; i++) {
         if (c->dUnitCost[i]) (void)hipFree(c->dUnitCost[i]);
@@ -484,6 +487,14 @@ int crt_debug_read_timeline(crt_ctx* c, unsigned long long* out, size_t max_word
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (n) HIP_TRY(c, hipMemcpy(out, c->dTimeline, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     *n_words = n;
+    return CRT_OK;
+}
+
+int crt_debug_read_counters(crt_ctx* c, unsigned long long out[16])
+{
+    if (!c || !out) return CRT_EINVAL;
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipMemcpy(out, c->dCounters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 

@@ -33,6 +33,9 @@ constexpr uint32_t kBoostAfter = 300;
 #ifndef NODE_STEPS
 #define NODE_STEPS 2
 #endif
+#ifndef CRT_PROF
+#define CRT_PROF 0
+#endif
 #ifndef LEAF_PAIRS
 #define LEAF_PAIRS 1
 #endif
@@ -162,6 +165,10 @@ struct Stack {
     int* spill;  // arena slice of this lane: kStackEntries - cap entries are ever needed, kStackEntries reserved
     int cap;     // wave-uniform
     int sp;
+#if CRT_PROF // diagnostic build (tools/prof_build.sh): where a wavefront's cycles go, never compiled into the product
+    unsigned long long tNode = 0, tLeaf = 0;
+    uint32_t itNode = 0, itLeaf = 0, lanesNode = 0, lanesLeaf = 0;
+#endif
     __device__ __forceinline__ void push(int v)
     {
         if (sp < cap) lds[sp * 64] = v;
@@ -288,12 +295,23 @@ __device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes
         if ((innerMask | leafMask) == 0ull) break;
         if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3); // a wavefront on a long critical path stops queueing behind the others
         if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
+#if CRT_PROF
+            const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
             if (cur >= 0) nodeStepClosest<COUNT, BLOCK, OCT>(nodes, r, tmin, tcull, stack, cur, cntNodes);
 #pragma unroll
             for (int extra = 1; extra < NODE_STEPS; extra++) // more node steps per scheduling decision: fewer ballots/branches
                 if (cur >= 0) nodeStepClosest<COUNT, BLOCK, OCT>(nodes, r, tmin, tcull, stack, cur, cntNodes);
+#if CRT_PROF
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            stack.tNode += __builtin_amdgcn_s_memtime() - ts0; stack.itNode++; stack.lanesNode += __popcll(innerMask);
+#endif
             continue;
         }
+#if CRT_PROF
+        const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+        stack.itLeaf++; stack.lanesLeaf += __popcll(leafMask);
+#endif
         if ((cur < 0) & (cur != kDone)) {
             const uint32_t code = static_cast<uint32_t>(~cur);
             const uint32_t first = code >> 3, cnt = code & 7u;
@@ -339,6 +357,10 @@ __device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes
 #endif
             cur = stack.sp == 0 ? kDone : stack.pop();
         }
+#if CRT_PROF
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stack.tLeaf += __builtin_amdgcn_s_memtime() - tl0;
+#endif
     }
 }
 
@@ -357,12 +379,23 @@ __device__ __forceinline__ bool traceAnyOct(const float4* __restrict__ nodes, co
         if ((innerMask | leafMask) == 0ull) break;
         if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3);
         if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
+#if CRT_PROF
+            const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
             if (cur >= 0) nodeStepAny<COUNT, BLOCK, OCT>(nodes, r, tmin, tcull, stack, cur, cntNodes);
 #pragma unroll
-            for (int extra = 1; extra < NODE_STEPS; extra++) // more node steps per scheduling decision: fewer ballots/branches
+            for (int extra = 1; extra < NODE_STEPS; extra++)
                 if (cur >= 0) nodeStepAny<COUNT, BLOCK, OCT>(nodes, r, tmin, tcull, stack, cur, cntNodes);
+#if CRT_PROF
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            stack.tNode += __builtin_amdgcn_s_memtime() - ts0; stack.itNode++; stack.lanesNode += __popcll(innerMask);
+#endif
             continue;
         }
+#if CRT_PROF
+        const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+        stack.itLeaf++; stack.lanesLeaf += __popcll(leafMask);
+#endif
         if ((cur < 0) & (cur != kDone)) {
             const uint32_t code = static_cast<uint32_t>(~cur);
             const uint32_t first = code >> 3, cnt = code & 7u;
@@ -378,6 +411,10 @@ __device__ __forceinline__ bool traceAnyOct(const float4* __restrict__ nodes, co
             }
             cur = (occluded | (stack.sp == 0)) ? kDone : stack.pop();
         }
+#if CRT_PROF
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stack.tLeaf += __builtin_amdgcn_s_memtime() - tl0;
+#endif
     }
     return occluded;
 }
@@ -732,6 +769,10 @@ __global__ __launch_bounds__(64) void renderKernel(const RenderParams p)
     const bool active = (px < p.width) & (py < p.height);
 
     uint32_t cntNodes = 0, cntTris = 0, cntShadow = 0, cntClosest = 0;
+#if CRT_PROF
+    const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
+    unsigned long long pTNode = 0, pTLeaf = 0; uint32_t pItN = 0, pItL = 0, pLaN = 0, pLaL = 0;
+#endif
     uint32_t iters = 0; // traversal-loop iterations of this wavefront = its critical path, fed back as next frame's cost
     if (active) {
         const float4* nodes = reinterpret_cast<const float4*>(p.nodes);
@@ -776,6 +817,9 @@ __global__ __launch_bounds__(64) void renderKernel(const RenderParams p)
             prim = __float_as_uint(T[1].w);
         }
 
+#if CRT_PROF
+        pTNode = stack.tNode; pTLeaf = stack.tLeaf; pItN = stack.itNode; pItL = stack.itLeaf; pLaN = stack.lanesNode; pLaL = stack.lanesLeaf;
+#endif
         const uint32_t packed = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
         const size_t pix = static_cast<size_t>(py) * p.width + px;
         if (p.staging) p.rgba8[static_cast<size_t>((tile_y * p.tiles_x + tile_x) / p.n_ranks) * (kTile * kTile) + ly * kTile + lx] = packed;
@@ -800,6 +844,18 @@ __global__ __launch_bounds__(64) void renderKernel(const RenderParams p)
         p.timeline[3 * static_cast<size_t>(blockIdx.x) + 1] = t_end;
         p.timeline[3 * static_cast<size_t>(blockIdx.x) + 2] = (static_cast<unsigned long long>(xcc) << 32) | (tile_y << 16) | tile_x;
     }
+#if CRT_PROF
+    if (p.counters) {
+        const unsigned long long tk = __builtin_amdgcn_s_memtime() - tk0;
+        // wave-uniform quantities: take them from the first active lane that has them (lane values are identical)
+        const unsigned long long m = __ballot(pItN | pItL);
+        if (m && lane == static_cast<uint32_t>(__ffsll(static_cast<long long>(m)) - 1)) {
+            atomicAdd(&p.counters[4], tk); atomicAdd(&p.counters[5], pTNode); atomicAdd(&p.counters[6], pTLeaf);
+            atomicAdd(&p.counters[7], static_cast<unsigned long long>(pItN)); atomicAdd(&p.counters[8], static_cast<unsigned long long>(pItL));
+            atomicAdd(&p.counters[9], static_cast<unsigned long long>(pLaN)); atomicAdd(&p.counters[10], static_cast<unsigned long long>(pLaL));
+        }
+    }
+#endif
     if (COUNT) {
         const uint32_t a = waveSum(cntNodes), c = waveSum(cntTris), s = waveSum(cntShadow), q = waveSum(cntClosest);
         if (lane == 0) {

@@ -155,6 +155,9 @@ int crt_set_option(crt_ctx* ctx, const char* name, int value);
 /* diagnostics: with option "timeline" = 1 and counting enabled, a render records per workgroup {start, end} on the
  * 100 MHz s_memrealtime clock and (XCC id << 32 | tile_y << 16 | tile_x); this copies them out (3 words per workgroup) */
 int crt_debug_read_timeline(crt_ctx* ctx, unsigned long long* out, size_t max_words, size_t* n_words);
+/* raw device counters of the last counting render: [0] nodes [1] triangles [2] shadow rays [3] closest-hit rays; [4..10]
+ * are filled only by the CRT_PROF diagnostic build of the kernels (tools/prof_build.sh) */
+int crt_debug_read_counters(crt_ctx* ctx, unsigned long long out[16]);
 
 /* stream plumbing: run on an external hipStream_t (e.g. torch's current stream; NULL = HIP's default stream);
  * crt_reset_stream goes back to the context's private non-blocking stream */
