@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "crt_abi_version", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
     "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_set_option", "crt_debug_read_timeline", "crt_debug_read_counters", "crt_render_frame", "crt_render_frame_device",
     "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_untile_device", "crt_set_stream", "crt_reset_stream",
-    "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_build_host4",
+    "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_build_host4", "crt_build_stats",
     "crt_scene_load", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
     "crt_scene_add_material", "crt_scene_mesh_count", "crt_scene_mesh", "crt_scene_light_count", "crt_scene_light",
     "crt_scene_material_count", "crt_scene_material", "crt_scene_texture_count", "crt_scene_settings",
@@ -128,6 +128,7 @@ def lib():
                                          C.POINTER(u32), C.POINTER(u32)]),
         "crt_free": (None, [vp]),
         "crt_bvh_info4": (C.c_int, [vp, C.POINTER(u32), C.POINTER(u32)]),
+        "crt_build_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "crt_bvh_export4": (C.c_int, [vp, vp]),
         "crt_bvh_build_host4": (C.c_int, [vp, u32, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]),
         "crt_scene_load": (C.c_int, [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]),
@@ -512,6 +513,11 @@ class Renderer:
         shade = np.zeros(info["n_tris"], dtype=SHADE_DTYPE)
         self._ok(lib().crt_bvh_export(self.h, nodes.ctypes.data, tris.ctypes.data, shade.ctypes.data), "crt_bvh_export")
         return nodes, tris, shade
+
+    def build_stats(self):
+        a, b = C.c_double(), C.c_double()
+        self._ok(lib().crt_build_stats(self.h, C.byref(a), C.byref(b)), "crt_build_stats")
+        return {"upload_ms": a.value, "device_build_ms": b.value}
 
     def bvh_export4(self):
         a, b = C.c_uint32(), C.c_uint32()

@@ -173,7 +173,10 @@ void writeNode(crt_bvh_node& d, const TempNode& s)
 
 } // namespace
 
-void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
+// Flatten the meshes in InstanceID order: triangle records {v0, e1, e2, ids}, shading records, and per triangle its
+// bounds (6 floats: min xyz, max xyz) and box centroid (3 floats) -- 9 floats per triangle in boxCent.
+void flattenMeshes(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<crt_bvh_tri>& inTri, std::vector<crt_bvh_shade>& inShade,
+                   std::vector<float>& boxCent)
 {
     uint64_t total = 0;
     for (uint32_t m = 0; m < n_meshes; m++) {
@@ -182,20 +185,9 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
     }
     if (total >= (1ull << 28)) throw std::runtime_error("too many triangles (limit 2^28 - 1)");
     const uint32_t n = static_cast<uint32_t>(total);
-
-    out.nodes.clear();
-    out.nodes4.clear();
-    out.depth4 = 0;
-    out.tris.clear();
-    out.shade.clear();
-    out.maxDepth = 0;
-    if (n == 0) return;
-
-    // ---- flatten: per-triangle records in input order, bounds, centroids
-    std::vector<crt_bvh_tri> inTri(n);
-    std::vector<crt_bvh_shade> inShade(n);
-    std::vector<Box> primBox(n);
-    std::vector<float> cent(3 * static_cast<size_t>(n));
+    inTri.resize(n);
+    inShade.resize(n);
+    boxCent.resize(9 * static_cast<size_t>(n));
     uint32_t g = 0;
     for (uint32_t m = 0; m < n_meshes; m++) {
         const crt_mesh_view& M = meshes[m];
@@ -206,13 +198,14 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
             const float* B = M.xyz + 3 * static_cast<size_t>(i1);
             const float* C = M.xyz + 3 * static_cast<size_t>(i2);
             crt_bvh_tri& T = inTri[g];
+            float* bc = &boxCent[9 * static_cast<size_t>(g)];
             for (int k = 0; k < 3; k++) {
                 T.v0[k] = A[k];
                 T.e1[k] = B[k] - A[k];
                 T.e2[k] = C[k] - A[k];
-                primBox[g].mn[k] = fmin_sel(fmin_sel(A[k], B[k]), C[k]);
-                primBox[g].mx[k] = fmax_sel(fmax_sel(A[k], B[k]), C[k]);
-                cent[3 * static_cast<size_t>(g) + k] = (primBox[g].mn[k] + primBox[g].mx[k]) * 0.5f;
+                bc[k] = fmin_sel(fmin_sel(A[k], B[k]), C[k]);
+                bc[3 + k] = fmax_sel(fmax_sel(A[k], B[k]), C[k]);
+                bc[6 + k] = (bc[k] + bc[3 + k]) * 0.5f;
             }
             T.inst = m;
             T.prim = t;
@@ -226,6 +219,31 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
                 std::memcpy(S.n2, M.normals + 3 * static_cast<size_t>(i2), 12);
             }
         }
+    }
+}
+
+void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
+{
+    std::vector<crt_bvh_tri> inTri;
+    std::vector<crt_bvh_shade> inShade;
+    std::vector<float> boxCent;
+    flattenMeshes(meshes, n_meshes, inTri, inShade, boxCent);
+    const uint32_t n = static_cast<uint32_t>(inTri.size());
+
+    out.nodes.clear();
+    out.nodes4.clear();
+    out.depth4 = 0;
+    out.tris.clear();
+    out.shade.clear();
+    out.maxDepth = 0;
+    if (n == 0) return;
+
+    std::vector<Box> primBox(n);
+    std::vector<float> cent(3 * static_cast<size_t>(n));
+    for (uint32_t i = 0; i < n; i++) {
+        std::memcpy(primBox[i].mn, &boxCent[9 * static_cast<size_t>(i)], 12);
+        std::memcpy(primBox[i].mx, &boxCent[9 * static_cast<size_t>(i) + 3], 12);
+        std::memcpy(&cent[3 * static_cast<size_t>(i)], &boxCent[9 * static_cast<size_t>(i) + 6], 12);
     }
 
     std::vector<uint32_t> order(n), scratch(n);

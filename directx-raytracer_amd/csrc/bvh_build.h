@@ -8,6 +8,8 @@
 #include <cstdint>
 #include <vector>
 
+struct ihipStream_t;
+
 namespace crt {
 
 constexpr int kLeafMax = 4;       // triangles per leaf
@@ -26,7 +28,12 @@ struct Bvh {
 
 // meshes in InstanceID order; triangle gid = running ordinal over meshes. Throws std::runtime_error on bad input.
 void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out);
-// binary -> wide collapse (DESIGN.md "BVH4"); called by buildBvh
+// shared first step of both builders (see bvh_build.cpp)
+void flattenMeshes(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<crt_bvh_tri>& inTri, std::vector<crt_bvh_shade>& inShade,
+                   std::vector<float>& boxCent);
+// LBVH on the GPU (bvh_gpu.hip): same output layout, lower quality, much faster; throws std::runtime_error on HIP errors
+void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, struct ihipStream_t* stream, double* device_ms);
+// binary -> wide collapse (DESIGN.md "BVH4"); called by both builders
 void collapseBvh4(Bvh& bvh);
 
 } // namespace crt

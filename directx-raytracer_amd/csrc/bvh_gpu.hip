@@ -1,0 +1,367 @@
+// GPU BVH build: stands in for BuildRaytracingAccelerationStructure, which the reference
+// runs on the GPU at init (R/DXRTRenderer.cpp:548-806).  LBVH: 30-bit Morton codes of the quantised box centroids,
+// radix sort, Karras 2012 hierarchy, bottom-up exact box fitting, ranges of <= 4 triangles collapsed to leaves.
+// Specification = oracle/crt_oracle.c build_lbvh(); the two produce byte-identical trees (tests/test_gpu_parity.py).
+// The binary tree is copied back and collapsed to the 4-wide tree by the same host routine as the SAH path.
+// Quality is below the SAH builder's (about +37 % node fetches, 2x triangle tests on the 1M-triangle frame): it is the
+// fast option (option "gpu_build"), not the default.
+#include "bvh_build.h"
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <chrono>
+#include <climits>
+#include <cstring>
+#include <stdexcept>
+#include <string>
+
+namespace crt {
+namespace {
+
+#define GPU_TRY(expr)                                                                                          \
+    do {                                                                                                       \
+        hipError_t e_ = (expr);                                                                                \
+        if (e_ != hipSuccess) throw std::runtime_error(std::string(#expr " failed: ") + hipGetErrorString(e_)); \
+    } while (0)
+
+struct KNode { // Karras internal node
+    int left, right;   // >= 0 internal index, < 0: ~sorted leaf position
+    uint32_t lo, hi;   // range of sorted positions covered
+};
+
+// float <-> int such that signed int order == float order (for atomicMin/atomicMax on floats)
+__device__ __forceinline__ int orderedInt(float f)
+{
+    const int i = __float_as_int(f);
+    return i >= 0 ? i : i ^ 0x7FFFFFFF;
+}
+__device__ __forceinline__ float fromOrderedInt(int i) { return __int_as_float(i >= 0 ? i : i ^ 0x7FFFFFFF); }
+
+__global__ void initBoundsKernel(int* bounds)
+{
+    if (threadIdx.x < 3) bounds[threadIdx.x] = INT_MAX;      // min
+    else if (threadIdx.x < 6) bounds[threadIdx.x] = INT_MIN; // max
+}
+
+// centroid bounds: wave reduction, one atomic pair per wavefront and axis
+__global__ __launch_bounds__(256) void boundsKernel(const float* __restrict__ cent, uint32_t n, int* bounds)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    int mn[3] = { INT_MAX, INT_MAX, INT_MAX }, mx[3] = { INT_MIN, INT_MIN, INT_MIN };
+    if (i < n)
+        for (int a = 0; a < 3; a++) mn[a] = mx[a] = orderedInt(cent[3 * static_cast<size_t>(i) + a]);
+    for (int off = 32; off > 0; off >>= 1)
+        for (int a = 0; a < 3; a++) {
+            mn[a] = min(mn[a], __shfl_xor(mn[a], off, 64));
+            mx[a] = max(mx[a], __shfl_xor(mx[a], off, 64));
+        }
+    if ((threadIdx.x & 63u) == 0)
+        for (int a = 0; a < 3; a++) {
+            atomicMin(&bounds[a], mn[a]);
+            atomicMax(&bounds[3 + a], mx[a]);
+        }
+}
+
+__device__ __forceinline__ uint32_t expandBits10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+__device__ __forceinline__ uint32_t quant10(float f) { return f >= 0.0f ? (f < 1024.0f ? static_cast<uint32_t>(f) : 1023u) : 0u; }
+
+__global__ __launch_bounds__(256) void mortonKernel(const float* __restrict__ cent, uint32_t n, const int* __restrict__ bounds,
+                                                    unsigned long long* __restrict__ keys)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t q[3];
+    for (int a = 0; a < 3; a++) {
+        const float lo = fromOrderedInt(bounds[a]), hi = fromOrderedInt(bounds[3 + a]);
+        const float ext = hi - lo;
+        const float scale = ext > 0.0f ? 1024.0f / ext : 0.0f;
+        q[a] = quant10((cent[3 * static_cast<size_t>(i) + a] - lo) * scale);
+    }
+    const uint32_t code = (expandBits10(q[0]) << 2) | (expandBits10(q[1]) << 1) | expandBits10(q[2]);
+    keys[i] = (static_cast<unsigned long long>(code) << 32) | i;
+}
+
+__device__ __forceinline__ int delta64(const unsigned long long* __restrict__ keys, long long n, long long i, long long j)
+{
+    if (j < 0 || j >= n) return -1;
+    return __clzll(static_cast<long long>(keys[i] ^ keys[j]));
+}
+
+// Karras 2012, one thread per internal node
+__global__ __launch_bounds__(256) void hierarchyKernel(const unsigned long long* __restrict__ keys, uint32_t n, KNode* __restrict__ K,
+                                                       int* __restrict__ parentOfInternal, int* __restrict__ parentOfLeaf)
+{
+    const long long i = static_cast<long long>(blockIdx.x) * 256 + threadIdx.x;
+    const long long N = n;
+    if (i >= N - 1) return;
+    const int d = (delta64(keys, N, i, i + 1) - delta64(keys, N, i, i - 1)) < 0 ? -1 : 1;
+    const int dmin = delta64(keys, N, i, i - d);
+    long long lmax = 2;
+    while (delta64(keys, N, i, i + lmax * d) > dmin) lmax *= 2;
+    long long l = 0;
+    for (long long t = lmax / 2; t >= 1; t /= 2)
+        if (delta64(keys, N, i, i + (l + t) * d) > dmin) l += t;
+    const long long j = i + l * d;
+    const int dnode = delta64(keys, N, i, j);
+    long long sp = 0;
+    for (long long t = (l + 1) / 2;; t = (t + 1) / 2) {
+        if (delta64(keys, N, i, i + (sp + t) * d) > dnode) sp += t;
+        if (t == 1) break;
+    }
+    const long long gamma = i + sp * d + (d < 0 ? -1 : 0);
+    const long long lo = i < j ? i : j, hi = i < j ? j : i;
+    KNode k;
+    k.lo = static_cast<uint32_t>(lo);
+    k.hi = static_cast<uint32_t>(hi);
+    if (lo == gamma) { k.left = ~static_cast<int>(gamma); parentOfLeaf[gamma] = static_cast<int>(i); }
+    else { k.left = static_cast<int>(gamma); parentOfInternal[gamma] = static_cast<int>(i); }
+    if (hi == gamma + 1) { k.right = ~static_cast<int>(gamma + 1); parentOfLeaf[gamma + 1] = static_cast<int>(i); }
+    else { k.right = static_cast<int>(gamma + 1); parentOfInternal[gamma + 1] = static_cast<int>(i); }
+    K[i] = k;
+    if (i == 0) parentOfInternal[0] = -1;
+}
+
+struct Box6 { float mn[3], mx[3]; };
+
+// bottom-up exact boxes: the second thread to arrive at a node unions its children and moves on.  Workgroups on
+// different XCDs hand boxes to each other through memory, so every hop is fenced at agent scope on both sides
+// (MI355X: per-XCD L2s are not coherent; cdna_hip_programming.md Guideline 16).
+__global__ __launch_bounds__(256) void fitKernel(const KNode* __restrict__ K, const Box6* __restrict__ pbox, const unsigned long long* __restrict__ keys,
+                                                 uint32_t n, const int* __restrict__ parentOfInternal, const int* __restrict__ parentOfLeaf,
+                                                 Box6* nodeBox, unsigned int* flags)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    int p = parentOfLeaf[i];
+    while (p >= 0) {
+        __threadfence(); // release what this thread wrote below (if anything) before announcing arrival
+        if (atomicAdd(&flags[p], 1u) == 0u) return; // first arrival: the sibling subtree is not finished yet
+        __threadfence(); // acquire the sibling's boxes
+        const KNode k = K[p];
+        Box6 b;
+        for (int c = 0; c < 2; c++) {
+            const int ref = c == 0 ? k.left : k.right;
+            Box6 cb;
+            if (ref < 0) cb = pbox[static_cast<uint32_t>(keys[~ref] & 0xFFFFFFFFull)];
+            else {
+                const volatile Box6* src = nodeBox + ref; // written by another thread during this launch: do not cache in registers early
+                for (int a = 0; a < 3; a++) { cb.mn[a] = src->mn[a]; cb.mx[a] = src->mx[a]; }
+            }
+            if (c == 0) b = cb;
+            else
+                for (int a = 0; a < 3; a++) {
+                    b.mn[a] = b.mn[a] < cb.mn[a] ? b.mn[a] : cb.mn[a]; // same selects as the oracle's aabb_grow(l, r)
+                    b.mx[a] = b.mx[a] > cb.mx[a] ? b.mx[a] : cb.mx[a];
+                }
+        }
+        nodeBox[p] = b;
+        p = parentOfInternal[p];
+    }
+}
+
+__global__ __launch_bounds__(256) void keptKernel(const KNode* __restrict__ K, uint32_t nInternal, uint32_t* __restrict__ kept)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < nInternal) kept[i] = (K[i].hi - K[i].lo + 1u > static_cast<uint32_t>(kLeafMax)) ? 1u : 0u;
+}
+
+__device__ __forceinline__ int leafRefDev(uint32_t first, uint32_t count) { return ~static_cast<int>((first << 3) | count); }
+
+__global__ __launch_bounds__(256) void emitKernel(const KNode* __restrict__ K, const uint32_t* __restrict__ kept, const uint32_t* __restrict__ rank,
+                                                  const Box6* __restrict__ nodeBox, const Box6* __restrict__ pbox,
+                                                  const unsigned long long* __restrict__ keys, uint32_t nInternal, crt_bvh_node* __restrict__ out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nInternal || !kept[i]) return;
+    const KNode k = K[i];
+    Box6 b[2];
+    int ref[2];
+    for (int c = 0; c < 2; c++) {
+        const int ch = c == 0 ? k.left : k.right;
+        if (ch < 0) {
+            b[c] = pbox[static_cast<uint32_t>(keys[~ch] & 0xFFFFFFFFull)];
+            ref[c] = leafRefDev(static_cast<uint32_t>(~ch), 1u);
+        } else {
+            b[c] = nodeBox[ch];
+            const uint32_t cnt = K[ch].hi - K[ch].lo + 1u;
+            ref[c] = cnt <= static_cast<uint32_t>(kLeafMax) ? leafRefDev(K[ch].lo, cnt) : static_cast<int>(rank[ch]);
+        }
+    }
+    crt_bvh_node N;
+    N.lx0 = b[0].mn[0]; N.lx1 = b[0].mx[0]; N.ly0 = b[0].mn[1]; N.ly1 = b[0].mx[1]; N.lz0 = b[0].mn[2]; N.lz1 = b[0].mx[2];
+    N.rx0 = b[1].mn[0]; N.rx1 = b[1].mx[0]; N.ry0 = b[1].mn[1]; N.ry1 = b[1].mx[1]; N.rz0 = b[1].mn[2]; N.rz1 = b[1].mx[2];
+    N.left = ref[0]; N.right = ref[1]; N.pad0 = 0; N.pad1 = 0;
+    out[rank[i]] = N;
+}
+
+__global__ __launch_bounds__(256) void reorderKernel(const unsigned long long* __restrict__ keys, uint32_t n, const crt_bvh_tri* __restrict__ inTri,
+                                                     const crt_bvh_shade* __restrict__ inShade, crt_bvh_tri* __restrict__ tris,
+                                                     crt_bvh_shade* __restrict__ shade)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t src = static_cast<uint32_t>(keys[i] & 0xFFFFFFFFull);
+    tris[i] = inTri[src];
+    shade[i] = inShade[src];
+}
+
+struct DevBuf {
+    void* p = nullptr;
+    explicit DevBuf(size_t bytes) { GPU_TRY(hipMalloc(&p, bytes ? bytes : 16)); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+} // namespace
+
+void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipStream_t* stream, double* device_ms)
+{
+    std::vector<crt_bvh_tri> inTri;
+    std::vector<crt_bvh_shade> inShade;
+    std::vector<float> pboxCent; // per triangle: 6 floats box + 3 floats centroid (9 floats)
+    flattenMeshes(meshes, n_meshes, inTri, inShade, pboxCent);
+    const uint32_t n = static_cast<uint32_t>(inTri.size());
+    out.nodes.clear(); out.nodes4.clear(); out.tris.clear(); out.shade.clear();
+    out.maxDepth = 0; out.depth4 = 0;
+    if (device_ms) *device_ms = 0.0;
+    if (n == 0) return;
+
+    // split the interleaved host array into the two device arrays the kernels read
+    std::vector<Box6> hBox(n);
+    std::vector<float> hCent(3 * static_cast<size_t>(n));
+    for (uint32_t i = 0; i < n; i++) {
+        std::memcpy(&hBox[i], &pboxCent[9 * static_cast<size_t>(i)], sizeof(Box6));
+        std::memcpy(&hCent[3 * static_cast<size_t>(i)], &pboxCent[9 * static_cast<size_t>(i) + 6], 3 * sizeof(float));
+    }
+    out.tris.resize(n);
+    out.shade.resize(n);
+
+    if (n <= static_cast<uint32_t>(kLeafMax)) {
+        // one leaf, wrapped in a node whose right child is an empty leaf with the same box (as the SAH path does)
+        Box6 root = hBox[0];
+        for (uint32_t i = 1; i < n; i++)
+            for (int a = 0; a < 3; a++) {
+                root.mn[a] = root.mn[a] < hBox[i].mn[a] ? root.mn[a] : hBox[i].mn[a];
+                root.mx[a] = root.mx[a] > hBox[i].mx[a] ? root.mx[a] : hBox[i].mx[a];
+            }
+        crt_bvh_node N;
+        N.lx0 = N.rx0 = root.mn[0]; N.lx1 = N.rx1 = root.mx[0]; N.ly0 = N.ry0 = root.mn[1]; N.ly1 = N.ry1 = root.mx[1];
+        N.lz0 = N.rz0 = root.mn[2]; N.lz1 = N.rz1 = root.mx[2];
+        N.left = ~static_cast<int32_t>((0u << 3) | n);
+        N.right = ~static_cast<int32_t>(0);
+        N.pad0 = N.pad1 = 0;
+        out.nodes.push_back(N);
+        // keys sort by Morton code then ordinal; with <= 4 triangles do it on the host with the same rule
+        std::vector<unsigned long long> keys(n);
+        float lo[3], hi[3];
+        for (int a = 0; a < 3; a++) { lo[a] = hCent[a]; hi[a] = hCent[a]; }
+        for (uint32_t i = 1; i < n; i++)
+            for (int a = 0; a < 3; a++) {
+                const float c = hCent[3 * i + a];
+                lo[a] = lo[a] < c ? lo[a] : c;
+                hi[a] = hi[a] > c ? hi[a] : c;
+            }
+        auto expand = [](uint32_t v) { v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu; v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u; return v; };
+        for (uint32_t i = 0; i < n; i++) {
+            uint32_t q[3];
+            for (int a = 0; a < 3; a++) {
+                const float ext = hi[a] - lo[a];
+                const float f = (hCent[3 * i + a] - lo[a]) * (ext > 0.0f ? 1024.0f / ext : 0.0f);
+                q[a] = f >= 0.0f ? (f < 1024.0f ? static_cast<uint32_t>(f) : 1023u) : 0u;
+            }
+            keys[i] = (static_cast<unsigned long long>((expand(q[0]) << 2) | (expand(q[1]) << 1) | expand(q[2])) << 32) | i;
+        }
+        std::sort(keys.begin(), keys.end());
+        for (uint32_t i = 0; i < n; i++) {
+            out.tris[i] = inTri[keys[i] & 0xFFFFFFFFull];
+            out.shade[i] = inShade[keys[i] & 0xFFFFFFFFull];
+        }
+        out.maxDepth = 1;
+        collapseBvh4(out);
+        return;
+    }
+
+    const uint32_t nInternal = n - 1;
+    DevBuf dBox(sizeof(Box6) * n), dCent(sizeof(float) * 3 * n), dBounds(sizeof(int) * 6);
+    DevBuf dKeysIn(sizeof(unsigned long long) * n), dKeys(sizeof(unsigned long long) * n);
+    DevBuf dK(sizeof(KNode) * nInternal), dParI(sizeof(int) * nInternal), dParL(sizeof(int) * n);
+    DevBuf dNodeBox(sizeof(Box6) * nInternal), dFlags(sizeof(unsigned int) * nInternal);
+    DevBuf dKept(sizeof(uint32_t) * nInternal), dRank(sizeof(uint32_t) * nInternal);
+    DevBuf dInTri(sizeof(crt_bvh_tri) * n), dInShade(sizeof(crt_bvh_shade) * n), dTris(sizeof(crt_bvh_tri) * n), dShade(sizeof(crt_bvh_shade) * n);
+    size_t sortBytes = 0, scanBytes = 0;
+    GPU_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sortBytes, dKeysIn.as<unsigned long long>(), dKeys.as<unsigned long long>(), static_cast<int>(n), 0, 62, stream));
+    GPU_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, dKept.as<uint32_t>(), dRank.as<uint32_t>(), static_cast<int>(nInternal), stream));
+    DevBuf dTemp(sortBytes > scanBytes ? sortBytes : scanBytes);
+
+    GPU_TRY(hipMemcpyAsync(dBox.p, hBox.data(), sizeof(Box6) * n, hipMemcpyHostToDevice, stream));
+    GPU_TRY(hipMemcpyAsync(dCent.p, hCent.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, stream));
+    GPU_TRY(hipMemcpyAsync(dInTri.p, inTri.data(), sizeof(crt_bvh_tri) * n, hipMemcpyHostToDevice, stream));
+    GPU_TRY(hipMemcpyAsync(dInShade.p, inShade.data(), sizeof(crt_bvh_shade) * n, hipMemcpyHostToDevice, stream));
+
+    hipEvent_t e0, e1;
+    GPU_TRY(hipEventCreate(&e0));
+    GPU_TRY(hipEventCreate(&e1));
+    GPU_TRY(hipEventRecord(e0, stream));
+    const dim3 blk(256), grdN((n + 255) / 256), grdI((nInternal + 255) / 256);
+    hipLaunchKernelGGL(initBoundsKernel, dim3(1), dim3(64), 0, stream, dBounds.as<int>());
+    hipLaunchKernelGGL(boundsKernel, grdN, blk, 0, stream, dCent.as<float>(), n, dBounds.as<int>());
+    hipLaunchKernelGGL(mortonKernel, grdN, blk, 0, stream, dCent.as<float>(), n, dBounds.as<int>(), dKeysIn.as<unsigned long long>());
+    GPU_TRY(hipcub::DeviceRadixSort::SortKeys(dTemp.p, sortBytes, dKeysIn.as<unsigned long long>(), dKeys.as<unsigned long long>(), static_cast<int>(n), 0, 62, stream));
+    hipLaunchKernelGGL(hierarchyKernel, grdI, blk, 0, stream, dKeys.as<unsigned long long>(), n, dK.as<KNode>(), dParI.as<int>(), dParL.as<int>());
+    GPU_TRY(hipMemsetAsync(dFlags.p, 0, sizeof(unsigned int) * nInternal, stream));
+    hipLaunchKernelGGL(fitKernel, grdN, blk, 0, stream, dK.as<KNode>(), dBox.as<Box6>(), dKeys.as<unsigned long long>(), n, dParI.as<int>(),
+                       dParL.as<int>(), dNodeBox.as<Box6>(), dFlags.as<unsigned int>());
+    hipLaunchKernelGGL(keptKernel, grdI, blk, 0, stream, dK.as<KNode>(), nInternal, dKept.as<uint32_t>());
+    GPU_TRY(hipcub::DeviceScan::ExclusiveSum(dTemp.p, scanBytes, dKept.as<uint32_t>(), dRank.as<uint32_t>(), static_cast<int>(nInternal), stream));
+    uint32_t lastKept = 0, lastRank = 0;
+    GPU_TRY(hipMemcpyAsync(&lastKept, dKept.as<uint32_t>() + (nInternal - 1), 4, hipMemcpyDeviceToHost, stream));
+    GPU_TRY(hipMemcpyAsync(&lastRank, dRank.as<uint32_t>() + (nInternal - 1), 4, hipMemcpyDeviceToHost, stream));
+    GPU_TRY(hipStreamSynchronize(stream));
+    const uint32_t nKept = lastKept + lastRank;
+    DevBuf dNodes(sizeof(crt_bvh_node) * nKept);
+    hipLaunchKernelGGL(emitKernel, grdI, blk, 0, stream, dK.as<KNode>(), dKept.as<uint32_t>(), dRank.as<uint32_t>(), dNodeBox.as<Box6>(), dBox.as<Box6>(),
+                       dKeys.as<unsigned long long>(), nInternal, dNodes.as<crt_bvh_node>());
+    hipLaunchKernelGGL(reorderKernel, grdN, blk, 0, stream, dKeys.as<unsigned long long>(), n, dInTri.as<crt_bvh_tri>(), dInShade.as<crt_bvh_shade>(),
+                       dTris.as<crt_bvh_tri>(), dShade.as<crt_bvh_shade>());
+    GPU_TRY(hipGetLastError());
+    GPU_TRY(hipEventRecord(e1, stream));
+    out.nodes.resize(nKept);
+    GPU_TRY(hipMemcpyAsync(out.nodes.data(), dNodes.p, sizeof(crt_bvh_node) * nKept, hipMemcpyDeviceToHost, stream));
+    GPU_TRY(hipMemcpyAsync(out.tris.data(), dTris.p, sizeof(crt_bvh_tri) * n, hipMemcpyDeviceToHost, stream));
+    GPU_TRY(hipMemcpyAsync(out.shade.data(), dShade.p, sizeof(crt_bvh_shade) * n, hipMemcpyDeviceToHost, stream));
+    GPU_TRY(hipStreamSynchronize(stream));
+    float ms = 0.f;
+    GPU_TRY(hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (device_ms) *device_ms = ms;
+
+    // depth of the binary tree (levels of nodes + the leaf level), then the shared host collapse to the wide tree
+    {
+        std::vector<std::pair<int32_t, uint32_t>> st;
+        st.emplace_back(0, 0u);
+        uint32_t deepest = 1;
+        while (!st.empty()) {
+            const auto [idx, d] = st.back();
+            st.pop_back();
+            if (d + 1 > deepest) deepest = d + 1;
+            if (out.nodes[idx].left >= 0) st.emplace_back(out.nodes[idx].left, d + 1);
+            if (out.nodes[idx].right >= 0) st.emplace_back(out.nodes[idx].right, d + 1);
+        }
+        out.maxDepth = deepest;
+    }
+    collapseBvh4(out);
+}
+
+} // namespace crt

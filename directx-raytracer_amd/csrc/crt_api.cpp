@@ -41,6 +41,9 @@ struct crt_ctx {
     void* dMats = nullptr;
     uint32_t nLights = 0, nMats = 0;
     bool haveScene = false;
+    bool gpuBuild = false;      // option "gpu_build": LBVH on the device instead of the host SAH builder
+    double buildMs = 0.0;       // wall time of the last crt_upload_scene (build + upload)
+    double buildDeviceMs = 0.0; // of which GPU kernels (gpu_build only)
     uint32_t sceneSerial = 0;
 
     float pos[3] = { 0.f, 0.f, 0.f };
@@ -370,8 +373,15 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
 {
     if (!c) return CRT_EINVAL;
     if ((!meshes && n_meshes) || (!lights && n_lights) || (!materials && n_materials)) return fail(c, CRT_EINVAL, "NULL array with non-zero count");
+    const auto tb0 = std::chrono::steady_clock::now();
+    c->buildDeviceMs = 0.0;
     try {
-        crt::buildBvh(meshes, n_meshes, c->bvh);
+        if (c->gpuBuild) {
+            HIP_TRY(c, hipSetDevice(c->device));
+            crt::buildBvhGpu(meshes, n_meshes, c->bvh, c->stream, &c->buildDeviceMs);
+        } else {
+            crt::buildBvh(meshes, n_meshes, c->bvh);
+        }
     } catch (const std::bad_alloc&) {
         return fail(c, CRT_ENOMEM, "out of host memory while building the BVH");
     } catch (const std::exception& ex) {
@@ -396,6 +406,7 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     if (n_materials) HIP_TRY(c, hipMemcpy(c->dMats, materials, sizeof(crt_material) * n_materials, hipMemcpyHostToDevice));
     c->nLights = n_lights;
     c->nMats = n_materials;
+    c->buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
     c->haveScene = true;
     c->sceneSerial++;
     c->orderKey[0] = c->orderKey[1] = 0;
@@ -436,6 +447,10 @@ int crt_set_counting(crt_ctx* c, int enabled)
 int crt_set_option(crt_ctx* c, const char* name, int value)
 {
     if (!c || !name) return CRT_EINVAL;
+    if (std::strcmp(name, "gpu_build") == 0) {
+        c->gpuBuild = value != 0;
+        return CRT_OK;
+    }
     if (std::strcmp(name, "spp") == 0 && value >= 1 && value <= 65536) {
         c->pathSpp = static_cast<uint32_t>(value);
         return CRT_OK;
@@ -609,6 +624,14 @@ int crt_bvh_info(const crt_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t
     if (n_nodes) *n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
     if (n_tris) *n_tris = static_cast<uint32_t>(c->bvh.tris.size());
     if (max_depth) *max_depth = c->bvh.maxDepth;
+    return CRT_OK;
+}
+
+int crt_build_stats(const crt_ctx* c, double* upload_ms, double* device_build_ms)
+{
+    if (!c || !c->haveScene) return CRT_ESTATE;
+    if (upload_ms) *upload_ms = c->buildMs;
+    if (device_build_ms) *device_build_ms = c->buildDeviceMs;
     return CRT_OK;
 }
 

@@ -147,7 +147,8 @@ int crt_render_tiles_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint3
 int crt_untile_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_ranks,
                       const void* d_gathered, void* d_rgba8_rowmajor);
 
-/* options. Rendering parameters of mode 200: "spp", "max_bounces", "seed". Tuning knobs (speed only, results never
+/* options. "gpu_build" 0/1: acceleration structure built on the GPU (LBVH) at the next crt_upload_scene.
+ * Rendering parameters of mode 200: "spp", "max_bounces", "seed". Tuning knobs (speed only, results never
  * change): "inner_min" 1..65 wave scheduling of the traversal loop, "xcd_group", "adaptive_order" 0/1, "boost_units",
  * "stack_entries" (0 = from the BVH depth). Diagnostics: "timeline" 0/1. */
 int crt_set_option(crt_ctx* ctx, const char* name, int value);
@@ -168,6 +169,9 @@ int crt_synchronize(crt_ctx* ctx);
 /* BVH introspection (tests, tooling): sizes, then copies of the host-side arrays uploaded to HBM */
 int crt_bvh_info(const crt_ctx* ctx, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* max_depth);
 int crt_bvh_export(const crt_ctx* ctx, crt_bvh_node* nodes, crt_bvh_tri* tris, crt_bvh_shade* shade);
+/* wall time of the last crt_upload_scene (flatten + build + collapse + upload) and, with option "gpu_build" = 1 (LBVH
+ * built by HIP kernels instead of the host SAH builder: faster build, slower traversal), the device time of the build kernels */
+int crt_build_stats(const crt_ctx* ctx, double* upload_ms, double* device_build_ms);
 /* the wide tree as it sits in HBM: count/depth (any pointer may be NULL), then a copy of the nodes */
 int crt_bvh_info4(const crt_ctx* ctx, uint32_t* n_nodes4, uint32_t* depth4);
 int crt_bvh_export4(const crt_ctx* ctx, crt_bvh_node4* nodes4);

@@ -322,9 +322,149 @@ static void build_wide(oracle_scene* s)
     s->depth4 = C.depth;
 }
 
+/* ------------------------------------------------------------------------------------------------
+ * LBVH (build mode 1): spec of the GPU builder.  Keys = 30-bit Morton code of the quantised box centroid (10 bits per
+ * axis over the centroid bounds) << 32 | input ordinal (unique, so the order is total); sorted ascending; hierarchy of
+ * Karras 2012 ("Maximizing parallelism in the construction of BVHs, octrees, and k-d trees") on the common-prefix
+ * length of the 64-bit keys; an internal node whose range holds <= LEAF_MAX triangles becomes a leaf; boxes are exact
+ * unions; kept internal nodes are numbered by ascending Karras index (the root is index 0).
+ * ---------------------------------------------------------------------------------------------- */
+static inline uint32_t expand_bits10(uint32_t v)
+{
+    v = (v * 0x00010001u) & 0xFF0000FFu;
+    v = (v * 0x00000101u) & 0x0F00F00Fu;
+    v = (v * 0x00000011u) & 0xC30C30C3u;
+    v = (v * 0x00000005u) & 0x49249249u;
+    return v;
+}
+static inline uint32_t quant10(float f) { return f >= 0.0f ? (f < 1024.0f ? (uint32_t)f : 1023u) : 0u; }
+static int cmp_u64(const void* a, const void* b)
+{
+    uint64_t x = *(const uint64_t*)a, y = *(const uint64_t*)b;
+    return x < y ? -1 : (x > y ? 1 : 0);
+}
+static inline int delta64(const uint64_t* keys, int64_t n, int64_t i, int64_t j)
+{
+    if (j < 0 || j >= n) return -1;
+    return __builtin_clzll(keys[i] ^ keys[j]);
+}
+
+typedef struct { int32_t left, right; /* >= 0 internal index, < 0: ~leaf position */ uint32_t lo, hi; } karras_node;
+
+static void lbvh_box(const karras_node* K, const aabb* sbox, int32_t ref, aabb* out, uint32_t depth, uint32_t* max_depth)
+{
+    if (ref < 0) { *out = sbox[~ref]; if (depth > *max_depth) *max_depth = depth; return; }
+    aabb l, r;
+    lbvh_box(K, sbox, K[ref].left, &l, depth + 1, max_depth);
+    lbvh_box(K, sbox, K[ref].right, &r, depth + 1, max_depth);
+    *out = l;
+    aabb_grow(out, &r);
+}
+
+/* fills order[] (sorted triangle permutation) and the binary nodes; returns node count */
+static uint32_t build_lbvh(const aabb* pbox, const float* pcent, uint32_t n, uint32_t* order, oracle_node* nodes, uint32_t* max_depth)
+{
+    aabb cb;
+    aabb_empty(&cb);
+    for (uint32_t i = 0; i < n; i++)
+        for (int a = 0; a < 3; a++) { cb.mn[a] = minf_(cb.mn[a], pcent[3 * i + a]); cb.mx[a] = maxf_(cb.mx[a], pcent[3 * i + a]); }
+    float scale[3];
+    for (int a = 0; a < 3; a++) { float ext = cb.mx[a] - cb.mn[a]; scale[a] = ext > 0.0f ? 1024.0f / ext : 0.0f; }
+    uint64_t* keys = (uint64_t*)malloc(sizeof(uint64_t) * n);
+    for (uint32_t i = 0; i < n; i++) {
+        uint32_t q[3];
+        for (int a = 0; a < 3; a++) q[a] = quant10((pcent[3 * i + a] - cb.mn[a]) * scale[a]);
+        uint32_t code = (expand_bits10(q[0]) << 2) | (expand_bits10(q[1]) << 1) | expand_bits10(q[2]);
+        keys[i] = ((uint64_t)code << 32) | i;
+    }
+    qsort(keys, n, sizeof(uint64_t), cmp_u64);
+    for (uint32_t i = 0; i < n; i++) order[i] = (uint32_t)(keys[i] & 0xFFFFFFFFu);
+    aabb* sbox = (aabb*)malloc(sizeof(aabb) * n);
+    for (uint32_t i = 0; i < n; i++) sbox[i] = pbox[order[i]];
+    *max_depth = 0;
+    if (n <= LEAF_MAX) { /* one leaf: wrapped by the caller like the SAH case */
+        free(keys); free(sbox);
+        return 0;
+    }
+    const int64_t N = n;
+    karras_node* K = (karras_node*)malloc(sizeof(karras_node) * (n - 1));
+    for (int64_t i = 0; i < N - 1; i++) {
+        int d = (delta64(keys, N, i, i + 1) - delta64(keys, N, i, i - 1)) < 0 ? -1 : 1;
+        int dmin = delta64(keys, N, i, i - d);
+        int64_t lmax = 2;
+        while (delta64(keys, N, i, i + lmax * d) > dmin) lmax *= 2;
+        int64_t l = 0;
+        for (int64_t t = lmax / 2; t >= 1; t /= 2)
+            if (delta64(keys, N, i, i + (l + t) * d) > dmin) l += t;
+        int64_t j = i + l * d;
+        int dnode = delta64(keys, N, i, j);
+        int64_t sp = 0;
+        for (int64_t t = (l + 1) / 2;; t = (t + 1) / 2) {
+            if (delta64(keys, N, i, i + (sp + t) * d) > dnode) sp += t;
+            if (t == 1) break;
+        }
+        int64_t gamma = i + sp * d + (d < 0 ? -1 : 0);
+        int64_t lo = i < j ? i : j, hi = i < j ? j : i;
+        K[i].lo = (uint32_t)lo; K[i].hi = (uint32_t)hi;
+        K[i].left = (lo == gamma) ? ~(int32_t)gamma : (int32_t)gamma;
+        K[i].right = (hi == gamma + 1) ? ~(int32_t)(gamma + 1) : (int32_t)(gamma + 1);
+    }
+    /* kept nodes: ranges of more than LEAF_MAX triangles, numbered by ascending index */
+    uint32_t* rank = (uint32_t*)malloc(sizeof(uint32_t) * (n - 1));
+    uint32_t kept = 0;
+    for (uint32_t i = 0; i + 1 < n; i++) { rank[i] = kept; if (K[i].hi - K[i].lo + 1 > LEAF_MAX) kept++; }
+    for (uint32_t i = 0; i + 1 < n; i++) {
+        if (K[i].hi - K[i].lo + 1 <= LEAF_MAX) continue;
+        oracle_node* Nn = &nodes[rank[i]];
+        aabb b[2];
+        int32_t ref[2];
+        const int32_t ch[2] = { K[i].left, K[i].right };
+        for (int c = 0; c < 2; c++) {
+            uint32_t dummy = 0;
+            lbvh_box(K, sbox, ch[c], &b[c], 0, &dummy);
+            if (ch[c] < 0) ref[c] = leaf_ref((uint32_t)~ch[c], 1);
+            else {
+                uint32_t cnt = K[ch[c]].hi - K[ch[c]].lo + 1;
+                ref[c] = cnt <= LEAF_MAX ? leaf_ref(K[ch[c]].lo, cnt) : (int32_t)rank[ch[c]];
+            }
+        }
+        Nn->lx0 = b[0].mn[0]; Nn->lx1 = b[0].mx[0]; Nn->ly0 = b[0].mn[1]; Nn->ly1 = b[0].mx[1]; Nn->lz0 = b[0].mn[2]; Nn->lz1 = b[0].mx[2];
+        Nn->rx0 = b[1].mn[0]; Nn->rx1 = b[1].mx[0]; Nn->ry0 = b[1].mn[1]; Nn->ry1 = b[1].mx[1]; Nn->rz0 = b[1].mn[2]; Nn->rz1 = b[1].mx[2];
+        Nn->left = ref[0]; Nn->right = ref[1]; Nn->pad0 = Nn->pad1 = 0;
+    }
+    /* depth of the emitted tree = deepest kept node + 1 (leaf level) */
+    {
+        uint32_t* dep = (uint32_t*)calloc(kept ? kept : 1, sizeof(uint32_t));
+        uint32_t deepest = 1;
+        for (uint32_t k = 0; k < kept; k++) { /* parents have smaller or larger Karras index: do a stack walk from the root */ (void)k; }
+        int32_t* st = (int32_t*)malloc(sizeof(int32_t) * (kept ? 2 * kept : 2));
+        uint32_t* sd = (uint32_t*)malloc(sizeof(uint32_t) * (kept ? 2 * kept : 2));
+        int top = 0;
+        st[top] = 0; sd[top++] = 0;
+        while (top) {
+            int32_t nidx = st[--top];
+            uint32_t d0 = sd[top];
+            if (d0 + 1 > deepest) deepest = d0 + 1;
+            if (nodes[nidx].left >= 0) { st[top] = nodes[nidx].left; sd[top++] = d0 + 1; }
+            if (nodes[nidx].right >= 0) { st[top] = nodes[nidx].right; sd[top++] = d0 + 1; }
+        }
+        *max_depth = deepest;
+        free(dep); free(st); free(sd);
+    }
+    free(keys); free(sbox); free(K); free(rank);
+    return kept;
+}
+
 oracle_scene* oracle_scene_create(const oracle_mesh* meshes, uint32_t n_meshes,
                                   const oracle_light* lights, uint32_t n_lights,
                                   const oracle_material* mats, uint32_t n_mats)
+{
+    return oracle_scene_create_ex(meshes, n_meshes, lights, n_lights, mats, n_mats, 0);
+}
+
+oracle_scene* oracle_scene_create_ex(const oracle_mesh* meshes, uint32_t n_meshes,
+                                     const oracle_light* lights, uint32_t n_lights,
+                                     const oracle_material* mats, uint32_t n_mats, int build_mode)
 {
     oracle_scene* s = (oracle_scene*)calloc(1, sizeof(*s));
     if (!s) return NULL;
@@ -382,7 +522,21 @@ oracle_scene* oracle_scene_create(const oracle_mesh* meshes, uint32_t n_meshes,
     B.n_nodes = 0; B.max_depth = 0;
     for (uint32_t i = 0; i < n; i++) B.order[i] = i;
 
-    if (n > 0) {
+    if (n > 0 && build_mode == 1) {
+        B.n_nodes = build_lbvh(pbox, pcent, n, B.order, B.nodes, &B.max_depth);
+        if (B.n_nodes == 0) { /* <= LEAF_MAX triangles: one leaf wrapped in a node, like the SAH case */
+            aabb rootbox;
+            aabb_empty(&rootbox);
+            for (uint32_t i = 0; i < n; i++) aabb_grow(&rootbox, &pbox[i]);
+            oracle_node* N = &B.nodes[0];
+            B.n_nodes = 1;
+            N->lx0 = N->rx0 = rootbox.mn[0]; N->lx1 = N->rx1 = rootbox.mx[0];
+            N->ly0 = N->ry0 = rootbox.mn[1]; N->ly1 = N->ry1 = rootbox.mx[1];
+            N->lz0 = N->rz0 = rootbox.mn[2]; N->lz1 = N->rz1 = rootbox.mx[2];
+            N->left = leaf_ref(0, n); N->right = leaf_ref(0, 0); N->pad0 = N->pad1 = 0;
+            B.max_depth = 1;
+        }
+    } else if (n > 0) {
         aabb rootbox;
         int32_t root = build_range(&B, 0, n, 0, &rootbox);
         if (root < 0) {

@@ -90,6 +90,11 @@ oracle_scene* oracle_scene_create(const oracle_mesh* meshes, uint32_t n_meshes,
                                   const oracle_light* lights, uint32_t n_lights,
                                   const oracle_material* mats, uint32_t n_mats);
 void oracle_scene_destroy(oracle_scene* s);
+/* build_mode 0: binned SAH (default, as oracle_scene_create); 1: LBVH (30-bit Morton codes + Karras 2012 hierarchy,
+ * ranges of <= 4 triangles collapsed to leaves) -- the spec of the product's GPU builder (csrc/bvh_gpu.hip) */
+oracle_scene* oracle_scene_create_ex(const oracle_mesh* meshes, uint32_t n_meshes,
+                                     const oracle_light* lights, uint32_t n_lights,
+                                     const oracle_material* mats, uint32_t n_mats, int build_mode);
 
 /* Replace the BVH by an externally built one (nodes + leaf-ordered triangles + shading records). */
 int oracle_scene_set_bvh(oracle_scene* s, const oracle_node* nodes, uint32_t n_nodes,

@@ -67,6 +67,8 @@ def lib():
         L = C.CDLL(_LIB_PATH)
         L.oracle_scene_create.restype = C.c_void_p
         L.oracle_scene_create.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32]
+        L.oracle_scene_create_ex.restype = C.c_void_p
+        L.oracle_scene_create_ex.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_uint32, C.c_int]
         L.oracle_scene_destroy.argtypes = [C.c_void_p]
         L.oracle_scene_set_bvh.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32]
         L.oracle_scene_set_width.argtypes = [C.c_void_p, C.c_int]
@@ -109,7 +111,8 @@ class OracleScene:
     """meshes: list of dicts {vertices (N,3) f32, triangles (M,3) u32, normals (N,3) f32|None, material_index}
     lights: list of (pos3, intensity); materials: list of dicts {albedo, type, smooth_shading, ior}."""
 
-    def __init__(self, meshes, lights=(), materials=()):
+    def __init__(self, meshes, lights=(), materials=(), build_mode=0):
+        """build_mode 0 = binned SAH, 1 = LBVH (spec of the GPU builder)"""
         L = lib()
         self._keep = []
         marr = (_Mesh * max(1, len(meshes)))()
@@ -137,7 +140,7 @@ class OracleScene:
             matarr[i].type = int(m.get("type", 1))
             matarr[i].smooth = int(bool(m.get("smooth_shading", False)))
             matarr[i].ior = float(m.get("ior", 1.0))
-        self.h = L.oracle_scene_create(marr, len(meshes), larr, len(lights), matarr, len(materials))
+        self.h = L.oracle_scene_create_ex(marr, len(meshes), larr, len(lights), matarr, len(materials), int(build_mode))
         if not self.h:
             raise RuntimeError("oracle_scene_create failed")
 
