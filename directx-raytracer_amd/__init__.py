@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_set_option", "crt_debug_read_timeline", "crt_debug_read_counters", "crt_render_frame", "crt_render_frame_device",
     "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_untile_device", "crt_set_stream", "crt_reset_stream",
     "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_build_host4", "crt_build_stats",
-    "crt_scene_load", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
+    "crt_scene_load", "crt_scene_save", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
     "crt_scene_add_material", "crt_scene_mesh_count", "crt_scene_mesh", "crt_scene_light_count", "crt_scene_light",
     "crt_scene_material_count", "crt_scene_material", "crt_scene_texture_count", "crt_scene_settings",
     "crt_scene_camera_get", "crt_scene_camera_set", "crt_scene_camera_rotate", "crt_scene_camera_zoom",
@@ -133,6 +133,7 @@ def lib():
         "crt_bvh_build_host4": (C.c_int, [vp, u32, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]),
         "crt_scene_load": (C.c_int, [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]),
         "crt_scene_new": (C.c_int, [C.POINTER(vp)]),
+        "crt_scene_save": (C.c_int, [vp, C.c_char_p, C.c_char_p, C.c_size_t]),
         "crt_scene_free": (None, [vp]),
         "crt_scene_add_mesh": (C.c_int, [vp, vp, u32, vp, u32, i32]),
         "crt_scene_add_light": (C.c_int, [vp, vp, f32]),
@@ -252,6 +253,13 @@ class Scene:
     def _ok(self, rc, what):
         if rc:
             raise CrtError("%s rc=%d" % (what, rc))
+
+    def save(self, path):
+        """binary cache (.crtbin)"""
+        err = C.create_string_buffer(512)
+        rc = lib().crt_scene_save(self.h, os.fsencode(path), err, len(err))
+        if rc:
+            raise CrtError("crt_scene_save(%s) rc=%d: %s" % (path, rc, err.value.decode()))
 
     def add_mesh(self, vertices, triangles, material_index=0):
         v = _f32(vertices).reshape(-1, 3)

@@ -694,6 +694,18 @@ int crt_scene_load(const char* path, crt_scene** out, char* err, size_t err_len)
     return CRT_OK;
 }
 
+int crt_scene_save(const crt_scene* s, const char* path, char* err, size_t err_len)
+{
+    if (!s || !path) return CRT_EINVAL;
+    try {
+        crt::SceneParser::saveBinary(path, s->scene);
+    } catch (const std::exception& ex) {
+        if (err && err_len) snprintf(err, err_len, "%s", ex.what());
+        return CRT_EIO;
+    }
+    return CRT_OK;
+}
+
 int crt_scene_new(crt_scene** out)
 {
     if (!out) return CRT_EINVAL;

@@ -83,6 +83,11 @@ public:
     void setMaterialIndex(int index) { materialIndex = index; }
     void addUV(const Vector& uv) { uvData.push_back(uv); }
     void reserve(size_t n_vertices, size_t n_indices);
+    // bulk setters used by the binary cache reader (the JSON path goes through addVertex/addIndex like the reference)
+    void assign(std::vector<Vector>&& v, std::vector<int>&& idx, std::vector<Vector>&& normals, std::vector<Vector>&& uvs)
+    {
+        vertices = std::move(v); indices = std::move(idx); vertexNormals = std::move(normals); uvData = std::move(uvs);
+    }
 
     const std::vector<Vector>& getVertices() const { return vertices; }
     const std::vector<int>& getIndices() const { return indices; }
@@ -209,8 +214,13 @@ private:
 
 class SceneParser {
 public:
-    // .crtscene JSON (R/CRTSceneParser.cpp:407-427) or Wavefront .obj (extension); throws std::runtime_error
+    // .crtscene JSON (R/CRTSceneParser.cpp:407-427), Wavefront .obj or the binary cache .crtbin (extensions);
+    // throws std::runtime_error
     static void parseScene(const std::string& sceneFileName, Scene& scene);
+    // binary scene cache: everything parseCrtscene produces, including the vertex normals,
+    // as raw little-endian arrays -- a 5M-triangle scene is ~0.5 GB of JSON text but 150 MB here and loads at memcpy speed
+    static void saveBinary(const std::string& fileName, const Scene& scene);
+    static void parseBinary(const std::string& bytes, Scene& scene);
     static void parseCrtscene(const std::string& text, Scene& scene);
     static void parseObj(const std::string& text, Scene& scene);
 };

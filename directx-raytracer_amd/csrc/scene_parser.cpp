@@ -6,6 +6,7 @@
 #include "scene.h"
 
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <sstream>
 #include <stdexcept>
@@ -235,10 +236,145 @@ void SceneParser::parseObj(const std::string& text, Scene& scene)
     scene.addMaterial(m);
 }
 
+// ---- binary scene cache (.crtbin) ------------------------------------------------------------------------------
+namespace {
+constexpr uint32_t kBinMagic = 0x42545243u; // "CRTB"
+constexpr uint32_t kBinVersion = 1;
+
+struct Writer {
+    std::ofstream out;
+    explicit Writer(const std::string& path) : out(path, std::ios::binary) { if (!out) throw std::runtime_error("cannot open '" + path + "' for writing"); }
+    template <class T> void pod(const T& v) { out.write(reinterpret_cast<const char*>(&v), sizeof(T)); }
+    void bytes(const void* p, size_t n) { out.write(static_cast<const char*>(p), static_cast<std::streamsize>(n)); }
+    void str(const std::string& s) { pod(static_cast<uint32_t>(s.size())); bytes(s.data(), s.size()); }
+    void vec(const Vector& v) { bytes(v.data(), 12); }
+};
+
+struct Reader {
+    const char* p;
+    const char* end;
+    template <class T> T pod()
+    {
+        if (static_cast<size_t>(end - p) < sizeof(T)) throw std::runtime_error("crtbin: truncated file");
+        T v;
+        std::memcpy(&v, p, sizeof(T));
+        p += sizeof(T);
+        return v;
+    }
+    void bytes(void* dst, size_t n)
+    {
+        if (static_cast<size_t>(end - p) < n) throw std::runtime_error("crtbin: truncated file");
+        std::memcpy(dst, p, n);
+        p += n;
+    }
+    std::string str()
+    {
+        const uint32_t n = pod<uint32_t>();
+        if (static_cast<size_t>(end - p) < n) throw std::runtime_error("crtbin: truncated file");
+        std::string s(p, n);
+        p += n;
+        return s;
+    }
+    Vector vec() { float f[3]; bytes(f, 12); return Vector(f[0], f[1], f[2]); }
+};
+} // namespace
+
+void SceneParser::saveBinary(const std::string& fileName, const Scene& scene)
+{
+    Writer w(fileName);
+    w.pod(kBinMagic);
+    w.pod(kBinVersion);
+    w.vec(scene.settings.backgroundColor);
+    w.pod(static_cast<int32_t>(scene.settings.imageWidth));
+    w.pod(static_cast<int32_t>(scene.settings.imageHeight));
+    w.vec(scene.camera.getPosition());
+    w.bytes(scene.camera.getRotationMatrix().data(), 36);
+    w.pod(static_cast<uint32_t>(scene.lights.size()));
+    for (const Light& l : scene.lights) { w.vec(l.getPosition()); w.pod(l.getIntensity()); }
+    w.pod(static_cast<uint32_t>(scene.materials.size()));
+    for (const Material& m : scene.materials) {
+        w.pod(static_cast<uint32_t>(m.getType()));
+        w.vec(m.getAlbedo());
+        w.pod(static_cast<uint32_t>(m.isSmoothShading() ? 1 : 0));
+        w.pod(m.getIor());
+        w.str(m.getTextureName());
+    }
+    w.pod(static_cast<uint32_t>(scene.textures.size()));
+    for (const TextureDesc& t : scene.textures) {
+        w.str(t.name); w.str(t.type); w.vec(t.colorA); w.vec(t.colorB); w.pod(t.scalar); w.str(t.filePath);
+    }
+    w.pod(static_cast<uint32_t>(scene.geometryObjects.size()));
+    for (const Mesh& m : scene.geometryObjects) {
+        w.pod(static_cast<int32_t>(m.getMaterialIndex()));
+        w.pod(static_cast<uint64_t>(m.getVertices().size()));
+        w.pod(static_cast<uint64_t>(m.getIndices().size()));
+        w.pod(static_cast<uint64_t>(m.getVertexNormals().size()));
+        w.pod(static_cast<uint64_t>(m.getUV().size()));
+        w.bytes(m.getVertices().data(), 12 * m.getVertices().size());
+        w.bytes(m.getIndices().data(), 4 * m.getIndices().size());
+        w.bytes(m.getVertexNormals().data(), 12 * m.getVertexNormals().size());
+        w.bytes(m.getUV().data(), 12 * m.getUV().size());
+    }
+    if (!w.out) throw std::runtime_error("write error on '" + fileName + "'");
+}
+
+void SceneParser::parseBinary(const std::string& bytes, Scene& scene)
+{
+    Reader r{ bytes.data(), bytes.data() + bytes.size() };
+    if (r.pod<uint32_t>() != kBinMagic) throw std::runtime_error("crtbin: bad magic");
+    if (r.pod<uint32_t>() != kBinVersion) throw std::runtime_error("crtbin: unsupported version");
+    scene.settings.backgroundColor = r.vec();
+    scene.settings.imageWidth = r.pod<int32_t>();
+    scene.settings.imageHeight = r.pod<int32_t>();
+    scene.camera.setPosition(r.vec());
+    float m[9];
+    r.bytes(m, 36);
+    scene.camera.setRotationMatrix(Matrix(m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7], m[8]));
+    for (uint32_t i = 0, n = r.pod<uint32_t>(); i < n; i++) {
+        const Vector pos = r.vec();
+        scene.lights.emplace_back(pos, r.pod<float>());
+    }
+    for (uint32_t i = 0, n = r.pod<uint32_t>(); i < n; i++) {
+        Material mat;
+        const uint32_t type = r.pod<uint32_t>();
+        if (type > 4) throw std::runtime_error("crtbin: bad material type");
+        mat.setType(static_cast<MaterialType>(type));
+        mat.setAlbedo(r.vec());
+        mat.setSmoothShading(r.pod<uint32_t>() != 0);
+        mat.setIor(r.pod<float>());
+        mat.setTextureName(r.str());
+        scene.materials.push_back(mat);
+    }
+    for (uint32_t i = 0, n = r.pod<uint32_t>(); i < n; i++) {
+        TextureDesc t;
+        t.name = r.str(); t.type = r.str(); t.colorA = r.vec(); t.colorB = r.vec(); t.scalar = r.pod<float>(); t.filePath = r.str();
+        scene.textures.push_back(t);
+    }
+    for (uint32_t i = 0, n = r.pod<uint32_t>(); i < n; i++) {
+        Mesh& mesh = scene.addObject();
+        mesh.setMaterialIndex(r.pod<int32_t>());
+        const uint64_t nv = r.pod<uint64_t>(), ni = r.pod<uint64_t>(), nn = r.pod<uint64_t>(), nu = r.pod<uint64_t>();
+        const uint64_t remaining = static_cast<uint64_t>(r.end - r.p);
+        if (nv > remaining / 12 || ni > remaining / 4 || nn > remaining / 12 || nu > remaining / 12 || ni % 3 != 0 || (nn != 0 && nn != nv))
+            throw std::runtime_error("crtbin: inconsistent mesh header");
+        std::vector<Vector> v(nv), nrm(nn), uv(nu);
+        std::vector<int> idx(ni);
+        r.bytes(v.data(), 12 * nv);
+        r.bytes(idx.data(), 4 * ni);
+        r.bytes(nrm.data(), 12 * nn);
+        r.bytes(uv.data(), 12 * nu);
+        for (int k : idx)
+            if (k < 0 || static_cast<uint64_t>(k) >= nv) throw std::runtime_error("crtbin: triangle index out of range");
+        mesh.assign(std::move(v), std::move(idx), std::move(nrm), std::move(uv));
+    }
+    if (r.p != r.end) throw std::runtime_error("crtbin: trailing bytes");
+}
+
 void SceneParser::parseScene(const std::string& sceneFileName, Scene& scene)
 {
     const std::string text = slurp(sceneFileName);
     if (endsWith(sceneFileName, ".obj")) parseObj(text, scene);
+    else if (endsWith(sceneFileName, ".crtbin")) parseBinary(text, scene);
     else parseCrtscene(text, scene);
 }
 

@@ -189,9 +189,12 @@ void crt_free(void* p);
 typedef struct crt_scene crt_scene;
 
 /* CRTScene::CRTScene(file) -> CRTSceneParser::parseScene (R/CRTScene.cpp:7-15, R/CRTSceneParser.cpp:407-427).
- * Accepts .crtscene (JSON) and, as an extension, .obj. Absent optional keys take defaults instead of the
+ * Accepts .crtscene (JSON) and, as extensions, .obj and the binary cache .crtbin. Absent optional keys take defaults instead of the
  * reference's undefined behaviour. */
 int crt_scene_load(const char* path, crt_scene** out, char* err, size_t err_len);
+/* binary scene cache (.crtbin): writes everything a .crtscene yields, vertex normals included,
+ * as raw arrays; crt_scene_load reads it back by extension at memcpy speed */
+int crt_scene_save(const crt_scene* s, const char* path, char* err, size_t err_len);
 /* empty scene to be filled programmatically */
 int crt_scene_new(crt_scene** out);
 void crt_scene_free(crt_scene* s);

@@ -153,3 +153,50 @@ def test_programmatic_scene_roundtrip(pkg, scenes):
     assert s.mesh_count == 6 and sum(len(m["triangles"]) for m in s.meshes()) == 32
     pos, rot = s.camera()
     np.testing.assert_array_equal(pos, sc["camera"]["position"])
+
+
+def test_binary_cache_roundtrip(pkg, scene, tmp_path, scenes):
+    """.crtbin holds everything the JSON scene yields (normals included) and loads back identically"""
+    p = str(tmp_path / "dragon.crtbin")
+    scene.save(p)
+    back = pkg.Scene(p)
+    assert back.mesh_count == scene.mesh_count
+    for i in range(scene.mesh_count):
+        a, b = scene.mesh(i), back.mesh(i)
+        for k in ("vertices", "triangles", "normals"):
+            np.testing.assert_array_equal(a[k], b[k])
+        assert a["material_index"] == b["material_index"]
+    assert back.lights() == scene.lights() and back.materials() == scene.materials() and back.settings() == scene.settings()
+    np.testing.assert_array_equal(back.camera()[0], scene.camera()[0])
+    np.testing.assert_array_equal(back.camera()[1], scene.camera()[1])
+    assert os.path.getsize(p) < 0.9 * os.path.getsize(os.path.join(os.path.dirname(__file__), "golden", "dragon.crtscene"))
+    # a synthetic mesh built through the C API survives too, and loads much faster than its JSON would parse
+    big = pkg.Scene.from_arrays(scenes.heightfield(n=120))
+    pb = str(tmp_path / "hf.crtbin")
+    big.save(pb)
+    b2 = pkg.Scene(pb)
+    np.testing.assert_array_equal(b2.mesh(1)["vertices"], big.mesh(1)["vertices"])
+    np.testing.assert_array_equal(b2.mesh(1)["normals"], big.mesh(1)["normals"])
+
+
+def test_binary_cache_rejects_damaged_files(pkg, scene, tmp_path):
+    p = str(tmp_path / "d.crtbin")
+    scene.save(p)
+    raw = open(p, "rb").read()
+    for name, data in (("trunc.crtbin", raw[:len(raw) // 2]), ("magic.crtbin", b"XXXX" + raw[4:]), ("tail.crtbin", raw + b"\\0"),
+                       ("ver.crtbin", raw[:4] + b"\\x09\\0\\0\\0" + raw[8:])):
+        q = tmp_path / name
+        q.write_bytes(data)
+        with pytest.raises(pkg.CrtError) as e:
+            pkg.Scene(str(q))
+        assert "rc=7" in str(e.value) and "crtbin" in str(e.value)
+    # index out of range inside an otherwise well-formed file
+    bad = bytearray(raw)
+    idx_pos = raw.rfind(np.uint32([0, 1, 2]).tobytes())  # first triangle of the ground quad
+    bad[idx_pos:idx_pos + 4] = np.uint32([0x7FFFFFFF]).tobytes()
+    q = tmp_path / "idx.crtbin"
+    q.write_bytes(bytes(bad))
+    with pytest.raises(pkg.CrtError):
+        pkg.Scene(str(q))
+    with pytest.raises(pkg.CrtError):
+        scene.save(str(tmp_path / "no_such_dir" / "x.crtbin"))
