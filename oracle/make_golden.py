@@ -8,6 +8,8 @@ a tool linked against the reference's CRT* sources compiled in place (oracle/Mak
                                          scene: sizeof()s, parse results, CRTMesh::calculateVertexNormals
                                          output (R/CRTMesh.cpp:66-94), CRTCamera operation sequences
                                          (R/CRTCamera.cpp:9-130), CRTVector*CRTMatrix (R/CRTMatrix.cpp:26-38)
+  tests/golden/texture_known_answers.json  getColor(u,v) of the reference's four texture classes (R/CRTTexture*.cpp) on a grid,
+                                         the bitmap one reading tests/golden/tex7x5.ppm (written here, seeded)
   tests/golden/dragon.crtscene           the same scene DATA re-serialised from the reference's parsed
                                          values (float32 printed with 9 significant digits round-trips
                                          exactly) so the GPU box, which has no /root/reference, can load it.
@@ -55,6 +57,16 @@ def main():
         del m["vertices"], m["indices"]
     with open(os.path.join(gold, "dragon_scene_layer.json"), "w") as f:
         json.dump(d, f, separators=(",", ":"))
+    # 3) texture classes: a small binary PPM the reference's vendored stb_image can decode, and getColor known answers
+    import numpy as np
+    rng = np.random.default_rng(11)
+    img = rng.integers(0, 256, size=(5, 7, 3), dtype=np.uint8)
+    with open(os.path.join(gold, "tex7x5.ppm"), "wb") as f:
+        f.write(b"P6\n7 5\n255\n" + img.tobytes())
+    ttmp = os.path.join(HERE, "_ref", "textures_ref.json")
+    subprocess.check_call([os.path.join(HERE, "_ref", "ref_dump"), "--textures", os.path.join(gold, "tex7x5.ppm"), ttmp])
+    with open(os.path.join(gold, "texture_known_answers.json"), "w") as f:
+        json.dump(json.load(open(ttmp)), f, separators=(",", ":"))
     print("wrote", gold)
     return 0
 

@@ -12,6 +12,10 @@
 // (R/CRTScene.h:21-36, R/CRTCamera.h:8-24, R/CRTMesh.h:10-23, R/CRTMatrix.h:12-18).
 #include "CRTScene.h"
 #include "CRTTriangle.h"
+#include "CRTTextureAlbedo.h"
+#include "CRTTextureBitmap.h"
+#include "CRTTextureChecker.h"
+#include "CRTTextureEdges.h"
 #include <cstdio>
 #include <cstdlib>
 #include <iostream>
@@ -43,6 +47,36 @@ static void putcam(FILE* f, const char* name, const CRTCamera& c, bool last = fa
 
 int main(int argc, char** argv)
 {
+    if (argc >= 4 && std::string(argv[1]) == "--textures") {
+        // known answers of the reference's texture classes (R/CRTTexture*.cpp getColor): argv[2] = a bitmap the vendored
+        // stb_image can read, argv[3] = output json
+        FILE* f = fopen(argv[3], "w");
+        if (!f) return 3;
+        CRTTextureAlbedo alb(CRTVector(0.25f, 0.5f, 0.75f), "a");
+        CRTTextureEdges edg(CRTVector(1.f, 0.f, 0.f), CRTVector(0.f, 0.f, 1.f), 0.1f, "e");
+        CRTTextureChecker chk(CRTVector(0.9f, 0.8f, 0.7f), CRTVector(0.1f, 0.2f, 0.3f), 0.125f, "c");
+        CRTTextureBitmap bmp(argv[2], "b");
+        const CRTTexture* tex[4] = { &alb, &edg, &chk, &bmp };
+        const char* names[4] = { "albedo", "edges", "checker", "bitmap" };
+        fprintf(f, "{\n \"params\":{\"albedo\":[0.25,0.5,0.75],\"edges\":{\"edge_color\":[1,0,0],\"inner_color\":[0,0,1],\"edge_width\":0.1},"
+                   "\"checker\":{\"color_A\":[0.9,0.8,0.7],\"color_B\":[0.1,0.2,0.3],\"square_size\":0.125}},\n");
+        for (int t = 0; t < 4; t++) {
+            fprintf(f, " \"%s\":[", names[t]);
+            bool first = true;
+            for (int iu = 0; iu <= 20; iu++)
+                for (int iv = 0; iv <= 20; iv++) {
+                    const float u = iu * 0.05f + (iu % 3) * 0.003f, v = iv * 0.05f + (iv % 4) * 0.002f;
+                    if (t == 1 && u + v > 1.0f) continue; // edges: barycentric domain
+                    const CRTVector c = tex[t]->getColor(u, v);
+                    fprintf(f, "%s[%.9g,%.9g,%.9g,%.9g,%.9g]", first ? "" : ",", u, v, c.getX(), c.getY(), c.getZ());
+                    first = false;
+                }
+            fprintf(f, "]%s\n", t < 3 ? "," : "");
+        }
+        fprintf(f, "}\n");
+        fclose(f);
+        return 0;
+    }
     if (argc < 3) { fprintf(stderr, "usage: ref_dump <scene.crtscene> <out.json>\n"); return 2; }
     // the reference parser chats on std::cout; keep it out of our way
     std::ostringstream sink;
