@@ -33,13 +33,14 @@ SHADE_DTYPE = np.dtype([("n0", "f4", 3), ("n1", "f4", 3), ("n2", "f4", 3), ("mat
 
 # every symbol include/crt_hip.h declares (tests/test_abi.py checks the library exports all of them)
 ABI_SYMBOLS = [
-    "crt_abi_version", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_camera",
+    "crt_abi_version", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_textures", "crt_bvh_export_uv", "crt_set_camera",
     "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_set_option", "crt_debug_read_timeline", "crt_debug_read_counters", "crt_render_frame", "crt_render_frame_device",
     "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_untile_device", "crt_set_stream", "crt_reset_stream",
     "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_build_host4", "crt_build_stats",
     "crt_scene_load", "crt_scene_save", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
     "crt_scene_add_material", "crt_scene_mesh_count", "crt_scene_mesh", "crt_scene_light_count", "crt_scene_light",
-    "crt_scene_material_count", "crt_scene_material", "crt_scene_texture_count", "crt_scene_settings",
+    "crt_scene_material_count", "crt_scene_material", "crt_scene_texture_count", "crt_scene_texture_color", "crt_scene_add_texture",
+    "crt_scene_set_material_texture", "crt_scene_set_mesh_uvs", "crt_scene_settings",
     "crt_scene_camera_get", "crt_scene_camera_set", "crt_scene_camera_rotate", "crt_scene_camera_zoom",
     "crt_scene_camera_move_forward", "crt_scene_camera_move_right", "crt_scene_camera_pan", "crt_scene_camera_tilt",
     "crt_scene_camera_roll", "crt_scene_camera_pan_around_target", "crt_upload_scene_from", "crt_set_camera_from",
@@ -51,7 +52,7 @@ class CrtError(RuntimeError):
 
 
 class MeshView(C.Structure):
-    _fields_ = [("xyz", C.c_void_p), ("idx", C.c_void_p), ("normals", C.c_void_p),
+    _fields_ = [("xyz", C.c_void_p), ("idx", C.c_void_p), ("normals", C.c_void_p), ("uvs", C.c_void_p),
                 ("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32), ("material_index", C.c_int32)]
 
 
@@ -60,7 +61,16 @@ class Light(C.Structure):
 
 
 class Material(C.Structure):
-    _fields_ = [("albedo", C.c_float * 3), ("type", C.c_uint32), ("smooth", C.c_uint32), ("ior", C.c_float)]
+    _fields_ = [("albedo", C.c_float * 3), ("type", C.c_uint32), ("smooth", C.c_uint32), ("ior", C.c_float), ("texture", C.c_int32)]
+
+
+class Texture(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("color_a", C.c_float * 3), ("color_b", C.c_float * 3), ("scalar", C.c_float),
+                ("pixels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint32)]
+
+
+TEXTURE_TYPES = {"albedo": 0, "edges": 1, "checker": 2, "bitmap": 3}
+UV_DTYPE = np.dtype([("uv0", "f4", 2), ("uv1", "f4", 2), ("uv2", "f4", 2)])
 
 
 class FrameStats(C.Structure):
@@ -107,6 +117,12 @@ def lib():
         "crt_last_error": (C.c_char_p, [vp]),
         "crt_upload_scene": (C.c_int, [vp, vp, u32, vp, u32, vp, u32]),
         "crt_set_camera": (C.c_int, [vp, vp, vp]),
+        "crt_set_textures": (C.c_int, [vp, vp, u32]),
+        "crt_bvh_export_uv": (C.c_int, [vp, vp, C.POINTER(C.c_int)]),
+        "crt_scene_texture_color": (C.c_int, [vp, u32, f32, f32, vp]),
+        "crt_scene_add_texture": (C.c_int, [vp, C.c_char_p, C.c_char_p, vp, vp, f32, C.c_char_p]),
+        "crt_scene_set_material_texture": (C.c_int, [vp, u32, C.c_char_p]),
+        "crt_scene_set_mesh_uvs": (C.c_int, [vp, u32, vp]),
         "crt_set_shading_mode": (C.c_int, [vp, u32]),
         "crt_set_miss_color": (C.c_int, [vp, vp]),
         "crt_set_counting": (C.c_int, [vp, C.c_int]),
@@ -234,6 +250,9 @@ class Scene:
             s.add_light(pos, inten)
         for m in sc.get("materials", []):
             s.add_material(m.get("albedo", (1, 1, 1)), m.get("type", 1), m.get("smooth_shading", False), m.get("ior", 1.0))
+        for i, m in enumerate(sc["meshes"]):
+            if m.get("uvs") is not None:
+                s.set_mesh_uvs(i, m["uvs"])
         cam = sc.get("camera")
         if cam is not None:
             s.set_camera(cam["position"], cam["matrix"])
@@ -271,8 +290,25 @@ class Scene:
         self._ok(lib().crt_scene_add_light(self.h, p.ctypes.data, float(intensity)), "crt_scene_add_light")
 
     def add_material(self, albedo=(1, 1, 1), type=1, smooth_shading=False, ior=1.0):
-        m = Material((C.c_float * 3)(*[float(x) for x in albedo]), int(type), int(bool(smooth_shading)), float(ior))
+        m = Material((C.c_float * 3)(*[float(x) for x in albedo]), int(type), int(bool(smooth_shading)), float(ior), -1)
         self._ok(lib().crt_scene_add_material(self.h, C.byref(m)), "crt_scene_add_material")
+
+    def add_texture(self, name, type, color_a=(0, 0, 0), color_b=(0, 0, 0), scalar=0.0, file_path=None):
+        a, b = _f32(color_a, 3), _f32(color_b, 3)
+        self._ok(lib().crt_scene_add_texture(self.h, name.encode(), type.encode(), a.ctypes.data, b.ctypes.data, float(scalar),
+                                             os.fsencode(file_path) if file_path else None), "crt_scene_add_texture")
+
+    def set_material_texture(self, material, texture_name):
+        self._ok(lib().crt_scene_set_material_texture(self.h, int(material), texture_name.encode()), "crt_scene_set_material_texture")
+
+    def set_mesh_uvs(self, mesh, uvs):
+        u = _f32(uvs).reshape(-1, 3)
+        self._ok(lib().crt_scene_set_mesh_uvs(self.h, int(mesh), u.ctypes.data), "crt_scene_set_mesh_uvs")
+
+    def texture_color(self, i, u, v):
+        out = np.zeros(3, dtype=np.float32)
+        self._ok(lib().crt_scene_texture_color(self.h, int(i), float(np.float32(u)), float(np.float32(v)), out.ctypes.data), "crt_scene_texture_color")
+        return out
 
     # ---- getters (CRTScene::getObjects / getLights / getMaterials / getTextures / getSettings)
     @property
@@ -291,7 +327,8 @@ class Scene:
         v = arr(mv.xyz, mv.n_vertices * 3, np.float32)
         t = arr(mv.idx, mv.n_triangles * 3, np.uint32)
         n = arr(mv.normals, mv.n_vertices * 3, np.float32)
-        return {"vertices": v.reshape(-1, 3) if v is not None else np.zeros((0, 3), np.float32),
+        uv = arr(mv.uvs, mv.n_vertices * 3, np.float32)
+        return {"uvs": uv.reshape(-1, 3) if uv is not None else None, "vertices": v.reshape(-1, 3) if v is not None else np.zeros((0, 3), np.float32),
                 "triangles": t.reshape(-1, 3) if t is not None else np.zeros((0, 3), np.uint32),
                 "normals": n.reshape(-1, 3) if n is not None else None, "material_index": mv.material_index}
 
@@ -311,7 +348,7 @@ class Scene:
         for i in range(lib().crt_scene_material_count(self.h)):
             m = Material()
             self._ok(lib().crt_scene_material(self.h, i, C.byref(m)), "crt_scene_material")
-            out.append({"albedo": tuple(m.albedo), "type": m.type, "smooth_shading": bool(m.smooth), "ior": m.ior})
+            out.append({"albedo": tuple(m.albedo), "type": m.type, "smooth_shading": bool(m.smooth), "ior": m.ior, "texture": m.texture})
         return out
 
     @property
@@ -371,10 +408,14 @@ def _mesh_views(meshes, keep):
         n = m.get("normals")
         if n is not None:
             n = _f32(n).reshape(-1, 3)
-        keep += [v, t, n]
+        uv = m.get("uvs")
+        if uv is not None:
+            uv = _f32(uv).reshape(-1, 3)
+        keep += [v, t, n, uv]
         arr[i].xyz = v.ctypes.data
         arr[i].idx = t.ctypes.data
         arr[i].normals = n.ctypes.data if n is not None else None
+        arr[i].uvs = uv.ctypes.data if uv is not None else None
         arr[i].n_vertices = len(v)
         arr[i].n_triangles = len(t)
         arr[i].material_index = int(m.get("material_index", 0))
@@ -444,7 +485,31 @@ class Renderer:
         if rc:
             raise CrtError("%s rc=%d: %s" % (what, rc, lib().crt_last_error(self.h).decode()))
 
-    def upload(self, meshes, lights=(), materials=()):
+    def set_textures(self, textures):
+        """textures: list of dicts {type: albedo|edges|checker|bitmap, color_a, color_b, scalar, pixels (H,W,C uint8)}"""
+        keep = []
+        arr = (Texture * max(1, len(textures)))()
+        for i, t in enumerate(textures):
+            arr[i].type = TEXTURE_TYPES[t["type"]]
+            arr[i].color_a = (C.c_float * 3)(*[float(c) for c in t.get("color_a", (0, 0, 0))])
+            arr[i].color_b = (C.c_float * 3)(*[float(c) for c in t.get("color_b", (0, 0, 0))])
+            arr[i].scalar = float(t.get("scalar", 0.0))
+            px = t.get("pixels")
+            if px is not None:
+                px = np.ascontiguousarray(px, dtype=np.uint8)
+                keep.append(px)
+                arr[i].pixels = px.ctypes.data
+                arr[i].height, arr[i].width, arr[i].channels = px.shape
+        self._ok(lib().crt_set_textures(self.h, arr, len(textures)), "crt_set_textures")
+
+    def bvh_export_uv(self):
+        info = self.bvh_info()
+        uv = np.zeros(info["n_tris"], dtype=UV_DTYPE)
+        has = C.c_int()
+        self._ok(lib().crt_bvh_export_uv(self.h, uv.ctypes.data, C.byref(has)), "crt_bvh_export_uv")
+        return uv if has.value else None
+
+    def upload(self, meshes, lights=(), materials=(), textures=None):
         keep = []
         mv = _mesh_views(meshes, keep)
         larr = (Light * max(1, len(lights)))()
@@ -457,7 +522,9 @@ class Renderer:
             marr[i].type = int(m.get("type", 1))
             marr[i].smooth = int(bool(m.get("smooth_shading", False)))
             marr[i].ior = float(m.get("ior", 1.0))
+            marr[i].texture = int(m.get("texture", -1))
         self._ok(lib().crt_upload_scene(self.h, mv, len(meshes), larr, len(lights), marr, len(materials)), "crt_upload_scene")
+        self.set_textures(list(textures) if textures else [])
 
     def upload_scene(self, scene):
         self._ok(lib().crt_upload_scene_from(self.h, scene.h), "crt_upload_scene_from")

@@ -222,6 +222,37 @@ void flattenMeshes(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<c
     }
 }
 
+void flattenUvs(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<crt_bvh_uv>& inUv)
+{
+    inUv.clear();
+    bool any = false;
+    uint64_t total = 0;
+    for (uint32_t m = 0; m < n_meshes; m++) {
+        any |= meshes[m].uvs != nullptr && meshes[m].n_triangles > 0;
+        total += meshes[m].n_triangles;
+    }
+    if (!any) return;
+    inUv.assign(total, crt_bvh_uv{});
+    uint32_t g = 0;
+    for (uint32_t m = 0; m < n_meshes; m++) {
+        const crt_mesh_view& M = meshes[m];
+        for (uint32_t t = 0; t < M.n_triangles; t++, g++) {
+            if (!M.uvs) continue;
+            std::memcpy(inUv[g].uv0, M.uvs + 3 * static_cast<size_t>(M.idx[3 * t]), 8);
+            std::memcpy(inUv[g].uv1, M.uvs + 3 * static_cast<size_t>(M.idx[3 * t + 1]), 8);
+            std::memcpy(inUv[g].uv2, M.uvs + 3 * static_cast<size_t>(M.idx[3 * t + 2]), 8);
+        }
+    }
+}
+
+void reorderUvs(const std::vector<crt_bvh_uv>& inUv, Bvh& bvh)
+{
+    bvh.uvs.clear();
+    if (inUv.empty()) return;
+    bvh.uvs.resize(bvh.tris.size());
+    for (size_t i = 0; i < bvh.tris.size(); i++) bvh.uvs[i] = inUv[bvh.tris[i].gid]; // gid = input ordinal
+}
+
 void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
 {
     std::vector<crt_bvh_tri> inTri;
@@ -236,6 +267,7 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
     out.tris.clear();
     out.shade.clear();
     out.maxDepth = 0;
+    out.uvs.clear();
     if (n == 0) return;
 
     std::vector<Box> primBox(n);
@@ -303,6 +335,9 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
         out.shade[i] = inShade[order[i]];
     }
     collapseBvh4(out);
+    std::vector<crt_bvh_uv> inUv;
+    flattenUvs(meshes, n_meshes, inUv);
+    reorderUvs(inUv, out);
 }
 
 // Binary -> 4-wide collapse.  A wide node takes the two children of a binary node and, while it has fewer than four

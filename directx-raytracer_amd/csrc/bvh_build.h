@@ -23,6 +23,7 @@ struct Bvh {
     uint32_t depth4 = 0;               // levels of the wide tree
     std::vector<crt_bvh_tri> tris;     // 48 B each, leaf order
     std::vector<crt_bvh_shade> shade;  // 48 B each, leaf order
+    std::vector<crt_bvh_uv> uvs;       // 24 B each, leaf order; empty when no mesh has uvs
     uint32_t maxDepth = 0;
 };
 
@@ -33,6 +34,9 @@ void flattenMeshes(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<c
                    std::vector<float>& boxCent);
 // LBVH on the GPU (bvh_gpu.hip): same output layout, lower quality, much faster; throws std::runtime_error on HIP errors
 void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, struct ihipStream_t* stream, double* device_ms);
+// per-triangle uvs in input (gid) order, empty when no mesh has any; and their permutation to leaf order
+void flattenUvs(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<crt_bvh_uv>& inUv);
+void reorderUvs(const std::vector<crt_bvh_uv>& inUv, Bvh& bvh);
 // binary -> wide collapse (DESIGN.md "BVH4"); called by both builders
 void collapseBvh4(Bvh& bvh);
 

@@ -234,6 +234,9 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
     const uint32_t n = static_cast<uint32_t>(inTri.size());
     out.nodes.clear(); out.nodes4.clear(); out.tris.clear(); out.shade.clear();
     out.maxDepth = 0; out.depth4 = 0;
+    out.uvs.clear();
+    std::vector<crt_bvh_uv> inUv;
+    flattenUvs(meshes, n_meshes, inUv);
     if (device_ms) *device_ms = 0.0;
     if (n == 0) return;
 
@@ -289,6 +292,7 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
         }
         out.maxDepth = 1;
         collapseBvh4(out);
+        reorderUvs(inUv, out);
         return;
     }
 
@@ -362,6 +366,7 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
         out.maxDepth = deepest;
     }
     collapseBvh4(out);
+    reorderUvs(inUv, out);
 }
 
 } // namespace crt

@@ -39,6 +39,10 @@ struct crt_ctx {
     void* dShade = nullptr;
     void* dLights = nullptr;
     void* dMats = nullptr;
+    void* dUvs = nullptr;
+    void* dTextures = nullptr;
+    void* dTexels = nullptr;
+    uint32_t nTextures = 0;
     uint32_t nLights = 0, nMats = 0;
     bool haveScene = false;
     bool gpuBuild = false;      // option "gpu_build": LBVH on the device instead of the host SAH builder
@@ -103,7 +107,7 @@ int fail(crt_ctx* ctx, int code, const char* fmt, ...)
 
 void freeScene(crt_ctx* c)
 {
-    void** ptrs[] = { &c->dNodes, &c->dTris, &c->dShade, &c->dLights, &c->dMats };
+    void** ptrs[] = { &c->dNodes, &c->dTris, &c->dShade, &c->dLights, &c->dMats, &c->dUvs };
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -132,6 +136,10 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.shade = c->dShade;
     p.lights = c->dLights;
     p.mats = c->dMats;
+    p.uvs = c->dUvs;
+    p.textures = c->dTextures;
+    p.texels = static_cast<const unsigned char*>(c->dTexels);
+    p.n_textures = c->nTextures;
     p.n_nodes = static_cast<uint32_t>(c->bvh.nodes4.size());
     p.n_tris = static_cast<uint32_t>(c->bvh.tris.size());
     p.n_lights = c->nLights;
@@ -324,6 +332,8 @@ void crt_destroy(crt_ctx* c)
     for (int i = 0; i < 5; i++)
         if (c->dFrame[i]) (void)hipFree(c->dFrame[i]);
     if (c->dCounters) (void)hipFree(c->dCounters);
+    if (c->dTextures) (void)hipFree(c->dTextures);
+    if (c->dTexels) (void)hipFree(c->dTexels);
     for (int i = 0; i < 2; i++)
         if (c->dSpill[i]) (void)hipFree(c->dSpill[i]);
     if (c->sideStream) (void)hipStreamSynchronize(c->sideStream);
@@ -402,6 +412,11 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     if (nb) HIP_TRY(c, hipMemcpy(c->dNodes, c->bvh.nodes4.data(), nb, hipMemcpyHostToDevice));
     if (tb) HIP_TRY(c, hipMemcpy(c->dTris, c->bvh.tris.data(), tb, hipMemcpyHostToDevice));
     if (sb) HIP_TRY(c, hipMemcpy(c->dShade, c->bvh.shade.data(), sb, hipMemcpyHostToDevice));
+    if (!c->bvh.uvs.empty()) {
+        const size_t ub = sizeof(crt_bvh_uv) * c->bvh.uvs.size();
+        HIP_TRY(c, hipMalloc(&c->dUvs, ub));
+        HIP_TRY(c, hipMemcpy(c->dUvs, c->bvh.uvs.data(), ub, hipMemcpyHostToDevice));
+    }
     if (n_lights) HIP_TRY(c, hipMemcpy(c->dLights, lights, sizeof(crt_light) * n_lights, hipMemcpyHostToDevice));
     if (n_materials) HIP_TRY(c, hipMemcpy(c->dMats, materials, sizeof(crt_material) * n_materials, hipMemcpyHostToDevice));
     c->nLights = n_lights;
@@ -410,6 +425,52 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     c->haveScene = true;
     c->sceneSerial++;
     c->orderKey[0] = c->orderKey[1] = 0;
+    return CRT_OK;
+}
+
+int crt_set_textures(crt_ctx* c, const crt_texture* textures, uint32_t n)
+{
+    if (!c) return CRT_EINVAL;
+    if (!textures && n) return fail(c, CRT_EINVAL, "crt_set_textures: NULL array with non-zero count");
+    std::vector<crt::TextureRec> recs(n);
+    std::vector<unsigned char> pool;
+    for (uint32_t i = 0; i < n; i++) {
+        const crt_texture& t = textures[i];
+        if (t.type > 3u) return fail(c, CRT_EINVAL, "texture %u: unknown type %u", i, t.type);
+        crt::TextureRec& r = recs[i];
+        r.type = t.type;
+        std::memcpy(r.a, t.color_a, 12);
+        std::memcpy(r.b, t.color_b, 12);
+        r.scalar = t.scalar;
+        r.texel_offset = r.width = r.height = r.channels = 0;
+        if (t.type == 3u) {
+            if (!t.pixels || t.width == 0 || t.height == 0 || t.channels < 3)
+                return fail(c, CRT_EINVAL, "texture %u: bitmap needs pixels, width, height and >= 3 channels", i);
+            const size_t bytes = static_cast<size_t>(t.width) * t.height * t.channels;
+            r.texel_offset = static_cast<uint32_t>(pool.size());
+            r.width = t.width; r.height = t.height; r.channels = t.channels;
+            pool.insert(pool.end(), t.pixels, t.pixels + bytes);
+        }
+    }
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (c->dTextures) (void)hipFree(c->dTextures);
+    if (c->dTexels) (void)hipFree(c->dTexels);
+    c->dTextures = c->dTexels = nullptr;
+    c->nTextures = 0;
+    HIP_TRY(c, hipMalloc(&c->dTextures, sizeof(crt::TextureRec) * (n + 1)));
+    HIP_TRY(c, hipMalloc(&c->dTexels, pool.size() + 16));
+    if (n) HIP_TRY(c, hipMemcpy(c->dTextures, recs.data(), sizeof(crt::TextureRec) * n, hipMemcpyHostToDevice));
+    if (!pool.empty()) HIP_TRY(c, hipMemcpy(c->dTexels, pool.data(), pool.size(), hipMemcpyHostToDevice));
+    c->nTextures = n;
+    return CRT_OK;
+}
+
+int crt_bvh_export_uv(const crt_ctx* c, crt_bvh_uv* uvs, int* has_uvs)
+{
+    if (!c || !c->haveScene) return CRT_ESTATE;
+    if (has_uvs) *has_uvs = c->bvh.uvs.empty() ? 0 : 1;
+    if (uvs && !c->bvh.uvs.empty()) std::memcpy(uvs, c->bvh.uvs.data(), sizeof(crt_bvh_uv) * c->bvh.uvs.size());
     return CRT_OK;
 }
 
@@ -758,6 +819,7 @@ int crt_scene_mesh(const crt_scene* s, uint32_t i, crt_mesh_view* out)
     out->idx = reinterpret_cast<const uint32_t*>(m.getIndices().data());
     out->normals = m.getVertexNormals().size() == m.getVertices().size() && !m.getVertexNormals().empty()
                        ? m.getVertexNormals().data()->data() : nullptr;
+    out->uvs = (m.getUV().size() == m.getVertices().size() && !m.getUV().empty()) ? m.getUV().data()->data() : nullptr;
     out->n_vertices = static_cast<uint32_t>(m.getVertices().size());
     out->n_triangles = static_cast<uint32_t>(m.getIndices().size() / 3);
     out->material_index = m.getMaterialIndex();
@@ -785,10 +847,59 @@ int crt_scene_material(const crt_scene* s, uint32_t i, crt_material* out)
     out->type = static_cast<uint32_t>(m.getType());
     out->smooth = m.isSmoothShading() ? 1u : 0u;
     out->ior = m.getIor();
+    out->texture = m.isTexture() ? s->scene.textureIndexByName(m.getTextureName()) : -1; // getTextureByName, R/CRTScene.cpp:52-63
     return CRT_OK;
 }
 
 uint32_t crt_scene_texture_count(const crt_scene* s) { return s ? static_cast<uint32_t>(s->scene.getTextures().size()) : 0; }
+
+int crt_scene_texture_color(const crt_scene* s, uint32_t i, float u, float v, float out_rgb[3])
+{
+    if (!s || !out_rgb || i >= s->scene.getTextures().size()) return CRT_EINVAL;
+    const crt::Vector c = s->scene.getTextures()[i].getColor(u, v);
+    std::memcpy(out_rgb, c.data(), 12);
+    return CRT_OK;
+}
+
+int crt_scene_add_texture(crt_scene* s, const char* name, const char* type, const float color_a[3], const float color_b[3], float scalar,
+                          const char* file_path)
+{
+    if (!s || !name || !type) return CRT_EINVAL;
+    crt::TextureDesc t;
+    t.name = name;
+    t.type = type;
+    if (t.type != "albedo" && t.type != "edges" && t.type != "checker" && t.type != "bitmap") return CRT_EINVAL;
+    if (color_a) t.colorA = crt::Vector(color_a[0], color_a[1], color_a[2]);
+    if (color_b) t.colorB = crt::Vector(color_b[0], color_b[1], color_b[2]);
+    t.scalar = scalar;
+    if (file_path) t.filePath = file_path;
+    if (t.typeCode() == 3u) {
+        try {
+            t.loadBitmap(std::string());
+        } catch (const std::exception&) {
+            return CRT_EIO;
+        }
+    }
+    s->scene.addTexture(t);
+    return CRT_OK;
+}
+
+int crt_scene_set_material_texture(crt_scene* s, uint32_t material, const char* texture_name)
+{
+    if (!s || !texture_name || material >= s->scene.getMaterials().size()) return CRT_EINVAL;
+    s->scene.materialsRef()[material].setTextureName(texture_name);
+    return CRT_OK;
+}
+
+int crt_scene_set_mesh_uvs(crt_scene* s, uint32_t mesh, const float* uvs)
+{
+    if (!s || !uvs || mesh >= s->scene.getObjects().size()) return CRT_EINVAL;
+    crt::Mesh& m = s->scene.objectsRef()[mesh];
+    std::vector<crt::Vector> uv(m.getVertices().size());
+    for (size_t i = 0; i < uv.size(); i++) uv[i] = crt::Vector(uvs[3 * i], uvs[3 * i + 1], uvs[3 * i + 2]);
+    m.setUVs(std::move(uv));
+    return CRT_OK;
+}
 
 int crt_scene_settings(const crt_scene* s, uint32_t* width, uint32_t* height, float background_rgb[3])
 {
@@ -850,7 +961,22 @@ int crt_upload_scene_from(crt_ctx* c, const crt_scene* s)
     for (uint32_t i = 0; i < nm; i++) crt_scene_mesh(s, i, &meshes[i]);
     for (uint32_t i = 0; i < nl; i++) crt_scene_light(s, i, &lights[i]);
     for (uint32_t i = 0; i < nmat; i++) crt_scene_material(s, i, &mats[i]);
-    const int rc = crt_upload_scene(c, meshes.data(), nm, lights.data(), nl, mats.data(), nmat);
+    int rc = crt_upload_scene(c, meshes.data(), nm, lights.data(), nl, mats.data(), nmat);
+    if (rc) return rc;
+    std::vector<crt_texture> tex;
+    for (const crt::TextureDesc& t : s->scene.getTextures()) {
+        crt_texture x{};
+        x.type = t.typeCode();
+        std::memcpy(x.color_a, t.colorA.data(), 12);
+        std::memcpy(x.color_b, t.colorB.data(), 12);
+        x.scalar = t.scalar;
+        x.pixels = t.pixels.empty() ? nullptr : t.pixels.data();
+        x.width = static_cast<uint32_t>(t.width);
+        x.height = static_cast<uint32_t>(t.height);
+        x.channels = static_cast<uint32_t>(t.channels);
+        tex.push_back(x);
+    }
+    rc = crt_set_textures(c, tex.data(), static_cast<uint32_t>(tex.size()));
     if (rc) return rc;
     return crt_set_camera_from(c, s);
 }

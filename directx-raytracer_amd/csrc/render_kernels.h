@@ -16,7 +16,11 @@ struct RenderParams {
     const void* tris;    // crt_bvh_tri[n_tris], 48 B
     const void* shade;   // crt_bvh_shade[n_tris], 48 B
     const void* lights;  // crt_light[n_lights]
-    const void* mats;    // crt_material[n_mats]
+    const void* mats;    // crt_material[n_mats] (28 B)
+    const void* uvs;     // crt_bvh_uv[n_tris] (24 B, leaf order) or null
+    const void* textures; // TextureRec[n_textures] (render_kernels.hip), bitmaps' texels in `texels`
+    const unsigned char* texels;
+    uint32_t n_textures;
     uint32_t n_nodes, n_tris, n_lights, n_mats;
     // per-frame constants: CameraCB (R/DXRTRenderer.h:54-59) + DebugCB (:68-72)
     float pos[3];
@@ -58,5 +62,13 @@ int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, ihipStrea
 // tile-major gathered buffer -> row-major frame
 int launchUntile(const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height, uint32_t n_ranks,
                  uint32_t slots, ihipStream_t* stream);
+
+// device-side texture record (crt_texture with the pixel pointer replaced by an offset into the texel pool)
+struct TextureRec {
+    uint32_t type;
+    float a[3], b[3];
+    float scalar;
+    uint32_t texel_offset, width, height, channels;
+};
 
 } // namespace crt

@@ -531,7 +531,30 @@ __device__ __forceinline__ F3 shadeDebug(uint32_t mode, uint32_t inst, uint32_t 
 }
 
 struct LightRec { float x, y, z, intensity; };
-struct MaterialRec { float r, g, b; uint32_t type; uint32_t smooth; float ior; };
+struct MaterialRec { float r, g, b; uint32_t type; uint32_t smooth; float ior; int texture; };
+
+// CRTTexture::getColor restated (R/CRTTexture*.cpp; oracle: texture_color)
+__device__ __forceinline__ F3 textureColor(const TextureRec& t, const unsigned char* texels, float u, float v)
+{
+    const F3 A = f3(t.a[0], t.a[1], t.a[2]), B = f3(t.b[0], t.b[1], t.b[2]);
+    if (t.type == 1u) return (u < t.scalar || v < t.scalar || (1.0f - u - v) < t.scalar) ? A : B; // edges
+    if (t.type == 2u) { // checker
+        const int width = static_cast<int>(1.0f / t.scalar);
+        const int u2 = static_cast<int>(floorf(u * static_cast<float>(width)));
+        const int v2 = static_cast<int>(floorf(v * static_cast<float>(width)));
+        return ((u2 + v2) % 2 == 0) ? A : B;
+    }
+    if (t.type == 3u) { // bitmap: nearest texel, v flipped
+        if (t.channels < 3u || t.width == 0u) return f3(0.0f, 0.0f, 0.0f);
+        u = fminf(fmaxf(u, 0.0f), 1.0f);
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        const int row = static_cast<int>((1.0f - v) * static_cast<float>(static_cast<int>(t.height) - 1));
+        const int col = static_cast<int>(u * static_cast<float>(static_cast<int>(t.width) - 1));
+        const unsigned char* px = texels + t.texel_offset + (static_cast<size_t>(row) * t.width + static_cast<size_t>(col)) * t.channels;
+        return f3(static_cast<float>(px[0]) / 255.0f, static_cast<float>(px[1]) / 255.0f, static_cast<float>(px[2]) / 255.0f);
+    }
+    return A; // albedo texture
+}
 
 // Surface at a closest hit (oracle: surface_at): hit point, shading normal flipped to face the ray, material
 struct Surface {
@@ -559,6 +582,22 @@ __device__ __forceinline__ Surface surfaceAt(const RenderParams& p, const float4
         smooth = M->smooth != 0;
         sf.mtype = M->type;
         sf.ior = M->ior;
+        if (M->texture >= 0 && static_cast<uint32_t>(M->texture) < p.n_textures) {
+            // CRTMaterial::isTexture: albedo from the texture; edges on the hit's barycentrics, the rest on the mesh uvs
+            const TextureRec tx = reinterpret_cast<const TextureRec*>(p.textures)[M->texture];
+            float tu = h.u, tv = h.v;
+            if (tx.type != 1u) {
+                tu = 0.0f;
+                tv = 0.0f;
+                if (p.uvs) {
+                    const float* U = reinterpret_cast<const float*>(p.uvs) + 6 * static_cast<size_t>(h.tri);
+                    const float w = 1.0f - h.u - h.v;
+                    tu = fmaf(U[4], h.v, fmaf(U[2], h.u, U[0] * w));
+                    tv = fmaf(U[5], h.v, fmaf(U[3], h.u, U[1] * w));
+                }
+            }
+            sf.albedo = textureColor(tx, p.texels, tu, tv);
+        }
     }
     F3 N = cross3(f3(tb.x, tb.y, tb.z), f3(tc.x, tc.y, tc.z));
     if (smooth) {

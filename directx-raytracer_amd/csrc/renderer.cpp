@@ -44,6 +44,7 @@ void Renderer::uploadScene()
         v.idx = reinterpret_cast<const uint32_t*>(m.getIndices().data());
         v.normals = (m.getVertexNormals().size() == m.getVertices().size() && !m.getVertices().empty())
                         ? m.getVertexNormals().data()->data() : nullptr;
+        v.uvs = (m.getUV().size() == m.getVertices().size() && !m.getUV().empty()) ? m.getUV().data()->data() : nullptr;
         v.n_vertices = static_cast<uint32_t>(m.getVertices().size());
         v.n_triangles = static_cast<uint32_t>(m.getIndices().size() / 3);
         v.material_index = m.getMaterialIndex();
@@ -55,10 +56,25 @@ void Renderer::uploadScene()
     std::vector<crt_material> mats;
     for (const Material& m : scene->getMaterials())
         mats.push_back(crt_material{ { m.getAlbedo().getX(), m.getAlbedo().getY(), m.getAlbedo().getZ() },
-                                     static_cast<uint32_t>(m.getType()), m.isSmoothShading() ? 1u : 0u, m.getIor() });
+                                     static_cast<uint32_t>(m.getType()), m.isSmoothShading() ? 1u : 0u, m.getIor(),
+                                     m.isTexture() ? scene->textureIndexByName(m.getTextureName()) : -1 });
     check(crt_upload_scene(ctx, meshes.data(), static_cast<uint32_t>(meshes.size()), lights.data(),
                            static_cast<uint32_t>(lights.size()), mats.data(), static_cast<uint32_t>(mats.size())),
           "crt_upload_scene");
+    std::vector<crt_texture> tex;
+    for (const TextureDesc& t : scene->getTextures()) {
+        crt_texture x{};
+        x.type = t.typeCode();
+        x.color_a[0] = t.colorA.getX(); x.color_a[1] = t.colorA.getY(); x.color_a[2] = t.colorA.getZ();
+        x.color_b[0] = t.colorB.getX(); x.color_b[1] = t.colorB.getY(); x.color_b[2] = t.colorB.getZ();
+        x.scalar = t.scalar;
+        x.pixels = t.pixels.empty() ? nullptr : t.pixels.data();
+        x.width = static_cast<uint32_t>(t.width);
+        x.height = static_cast<uint32_t>(t.height);
+        x.channels = static_cast<uint32_t>(t.channels);
+        tex.push_back(x);
+    }
+    check(crt_set_textures(ctx, tex.data(), static_cast<uint32_t>(tex.size())), "crt_set_textures");
 }
 
 void Renderer::render() { renderFrame(); }

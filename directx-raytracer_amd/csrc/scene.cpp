@@ -4,7 +4,9 @@
 
 #include <algorithm>
 #include <cmath>
+#include <fstream>
 #include <iostream>
+#include <stdexcept>
 
 namespace crt {
 
@@ -173,7 +175,81 @@ void Camera::panAroundTarget(float degrees, const Vector& target) // R/CRTCamera
     rotationMatrix = rotationMatrix * ry;
 }
 
+// -------------------------------------------------------------------------------------------- textures
+uint32_t TextureDesc::typeCode() const
+{
+    if (type == "edges") return 1u;
+    if (type == "checker") return 2u;
+    if (type == "bitmap") return 3u;
+    return 0u;
+}
+
+Vector TextureDesc::getColor(float u, float v) const
+{
+    switch (typeCode()) {
+    case 1u:
+        return (u < scalar || v < scalar || (1 - u - v) < scalar) ? colorA : colorB;
+    case 2u: {
+        const int n = static_cast<int>(1.f / scalar);
+        const int cu = static_cast<int>(std::floor(u * n)), cv = static_cast<int>(std::floor(v * n));
+        return ((cu + cv) % 2 == 0) ? colorA : colorB;
+    }
+    case 3u: {
+        if (pixels.empty() || channels < 3) return Vector(0.f, 0.f, 0.f);
+        u = std::fmin(std::fmax(u, 0.0f), 1.0f);
+        v = std::fmin(std::fmax(v, 0.0f), 1.0f);
+        const int row = static_cast<int>((1.0f - v) * (height - 1));
+        const int col = static_cast<int>(u * (width - 1));
+        const size_t at = (static_cast<size_t>(row) * width + col) * channels;
+        return Vector(pixels[at] / 255.0f, pixels[at + 1] / 255.0f, pixels[at + 2] / 255.0f);
+    }
+    default:
+        return colorA;
+    }
+}
+
+void TextureDesc::loadBitmap(const std::string& sceneDir)
+{
+    std::ifstream in(filePath, std::ios::binary);
+    if (!in && !sceneDir.empty()) in.open(sceneDir + "/" + filePath, std::ios::binary);
+    if (!in) throw std::runtime_error("cannot open texture file '" + filePath + "'");
+    std::string magic;
+    in >> magic;
+    if (magic != "P6" && magic != "P5") throw std::runtime_error("texture '" + filePath + "': only binary PPM/PGM (P6/P5) bitmaps are supported");
+    auto nextInt = [&]() {
+        for (;;) { // skip whitespace and # comments
+            const int c = in.peek();
+            if (c == '#') { std::string skip; std::getline(in, skip); }
+            else if (c == ' ' || c == '\n' || c == '\r' || c == '\t') in.get();
+            else break;
+        }
+        int v = -1;
+        in >> v;
+        return v;
+    };
+    const int w = nextInt(), h = nextInt(), maxv = nextInt();
+    in.get(); // the single whitespace byte after maxval
+    if (w <= 0 || h <= 0 || maxv != 255 || static_cast<long long>(w) * h > (1ll << 28)) throw std::runtime_error("texture '" + filePath + "': bad PNM header");
+    const int fileCh = magic == "P6" ? 3 : 1;
+    std::vector<unsigned char> raw(static_cast<size_t>(w) * h * fileCh);
+    in.read(reinterpret_cast<char*>(raw.data()), static_cast<std::streamsize>(raw.size()));
+    if (static_cast<size_t>(in.gcount()) != raw.size()) throw std::runtime_error("texture '" + filePath + "': truncated");
+    width = w; height = h; channels = 3;
+    if (fileCh == 3) pixels = std::move(raw);
+    else {
+        pixels.resize(static_cast<size_t>(w) * h * 3);
+        for (size_t i = 0; i < raw.size(); i++) pixels[3 * i] = pixels[3 * i + 1] = pixels[3 * i + 2] = raw[i];
+    }
+}
+
 // ----------------------------------------------------------------------------------------------- Scene
+int Scene::textureIndexByName(const std::string& name) const
+{
+    for (size_t i = 0; i < textures.size(); i++)
+        if (textures[i].name == name) return static_cast<int>(i);
+    return -1;
+}
+
 Scene::Scene(const std::string& sceneFileName) { parseSceneFile(sceneFileName); }
 
 void Scene::parseSceneFile(const std::string& sceneFileName) { SceneParser::parseScene(sceneFileName, *this); }

@@ -82,6 +82,7 @@ public:
     void addIndex(int index) { indices.push_back(index); }
     void setMaterialIndex(int index) { materialIndex = index; }
     void addUV(const Vector& uv) { uvData.push_back(uv); }
+    void setUVs(std::vector<Vector>&& uvs) { uvData = std::move(uvs); }
     void reserve(size_t n_vertices, size_t n_indices);
     // bulk setters used by the binary cache reader (the JSON path goes through addVertex/addIndex like the reference)
     void assign(std::vector<Vector>&& v, std::vector<int>&& idx, std::vector<Vector>&& normals, std::vector<Vector>&& uvs)
@@ -173,6 +174,17 @@ struct TextureDesc {
     Vector colorA, colorB;
     float scalar = 0.f; // edge_width / square_size
     std::string filePath;
+    // bitmap texels (rows top to bottom, `channels` bytes per texel), filled by loadBitmap()
+    std::vector<unsigned char> pixels;
+    int width = 0, height = 0, channels = 0;
+
+    // CRTTexture::getColor (R/CRTTextureAlbedo.cpp, R/CRTTextureEdges.cpp:9-15, R/CRTTextureChecker.cpp:9-20,
+    // R/CRTTextureBitmap.cpp:12-36); pinned by tests/golden/texture_known_answers.json
+    Vector getColor(float u = 0.f, float v = 0.f) const;
+    // binary PPM (P6) / PGM (P5, expanded to 3 channels); the reference decodes through stb_image, which is third party.
+    // Relative paths are tried as given and next to `sceneDir`. Throws std::runtime_error.
+    void loadBitmap(const std::string& sceneDir);
+    uint32_t typeCode() const; // 0 albedo, 1 edges, 2 checker, 3 bitmap (crt_texture.type)
 };
 
 struct Settings {
@@ -200,6 +212,10 @@ public:
     Mesh& addObject() { geometryObjects.emplace_back(); return geometryObjects.back(); }
     void addLight(const Light& l) { lights.push_back(l); }
     void addMaterial(const Material& m) { materials.push_back(m); }
+    void addTexture(const TextureDesc& t) { textures.push_back(t); }
+    std::vector<Material>& materialsRef() { return materials; }
+    std::vector<Mesh>& objectsRef() { return geometryObjects; }
+    int textureIndexByName(const std::string& name) const; // -1 when absent
     Settings& settingsRef() { return settings; }
 
 private:

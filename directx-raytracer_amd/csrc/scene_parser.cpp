@@ -376,6 +376,11 @@ void SceneParser::parseScene(const std::string& sceneFileName, Scene& scene)
     if (endsWith(sceneFileName, ".obj")) parseObj(text, scene);
     else if (endsWith(sceneFileName, ".crtbin")) parseBinary(text, scene);
     else parseCrtscene(text, scene);
+    // bitmap textures are decoded at load time, like CRTTextureBitmap's constructor does (R/CRTTextureBitmap.cpp:6-10)
+    const size_t slash = sceneFileName.find_last_of("/\\");
+    const std::string dir = slash == std::string::npos ? std::string() : sceneFileName.substr(0, slash);
+    for (TextureDesc& t : scene.textures)
+        if (t.typeCode() == 3u && t.pixels.empty()) t.loadBitmap(dir);
 }
 
 } // namespace crt

@@ -138,6 +138,36 @@ def cornell_box(width=256, height=256):
     return _scene(meshes, lights, mats, cam_pos=(0.0, 0.0, 15.0), cam_rot=IDENTITY, width=width, height=height)
 
 
+def textured_cornell(width=320, height=240):
+    """The Cornell box with per-vertex uvs and one texture of each kind the reference parses
+    (R/CRTSceneParser.cpp:221-306): checker walls, edges left wall, bitmap right wall, albedo-texture boxes."""
+    sc = cornell_box(width, height)
+    quad_uv = np.float32([[0, 0, 0], [1, 0, 0], [1, 1, 0], [0, 1, 0]])
+    for m in sc["meshes"]:
+        n = len(m["vertices"])
+        if n % 4 == 0 and n <= 12:
+            m["uvs"] = np.tile(quad_uv, (n // 4, 1))
+        else:  # the boxes: planar projection with values outside [0,1] and negative ones (floor() in the checker, clamps in the bitmap)
+            v = np.asarray(m["vertices"], dtype=np.float32)
+            m["uvs"] = np.stack([v[:, 0] * np.float32(0.37), v[:, 1] * np.float32(0.21) + v[:, 2] * np.float32(0.11), np.zeros(len(v), np.float32)], axis=1)
+    yy, xx = np.mgrid[0:13, 0:17]
+    pixels = np.stack([(xx * 15) % 256, (yy * 19) % 256, ((xx + yy) * 9) % 256], axis=-1).astype(np.uint8)
+    sc["textures"] = [
+        {"type": "checker", "color_a": (0.9, 0.9, 0.9), "color_b": (0.2, 0.2, 0.6), "scalar": 0.125},
+        {"type": "edges", "color_a": (1.0, 0.9, 0.1), "color_b": (0.65, 0.05, 0.05), "scalar": 0.04},
+        {"type": "bitmap", "pixels": pixels},
+        {"type": "albedo", "color_a": (0.3, 0.8, 0.4)},
+    ]
+    sc["materials"][0]["texture"] = 0
+    sc["materials"][1]["texture"] = 1
+    sc["materials"][2]["texture"] = 2
+    sc["materials"].append({"albedo": (0.5, 0.5, 0.5), "type": 1, "texture": 3})
+    sc["materials"].append({"albedo": (0.9, 0.9, 0.9), "type": 2, "texture": 0})  # a mirror ignores its texture
+    sc["meshes"][4]["material_index"] = 4
+    sc["meshes"][5]["material_index"] = 5
+    return sc
+
+
 # ----------------------------------------------------------------------------------------------------
 # C2: ~70k-triangle closed mesh (stand-in for the Stanford bunny, which cannot be fetched)
 # ----------------------------------------------------------------------------------------------------

@@ -57,13 +57,20 @@ typedef struct crt_mesh_view {
     const float* xyz;      /* n_vertices * 3                                  (CRTMesh::getVertices) */
     const uint32_t* idx;   /* n_triangles * 3                                 (CRTMesh::getIndices) */
     const float* normals;  /* n_vertices * 3 or NULL                          (CRTMesh::getVertexNormals) */
+    const float* uvs;      /* n_vertices * 3 (u, v, unused) or NULL           (CRTMesh::getUV) */
     uint32_t n_vertices;
     uint32_t n_triangles;
     int32_t material_index; /*                                                (CRTMesh::getMaterialIndex) */
 } crt_mesh_view;
 
 typedef struct crt_light { float pos[3]; float intensity; } crt_light;                 /* R/CRTLight.h:4-16 */
-typedef struct crt_material { float albedo[3]; uint32_t type; uint32_t smooth; float ior; } crt_material; /* R/CRTMaterial.h:4-36; type = CRTMaterialType */
+typedef struct crt_material { float albedo[3]; uint32_t type; uint32_t smooth; float ior; int32_t texture; } crt_material; /* R/CRTMaterial.h:4-36;
+    type = CRTMaterialType; texture = index into crt_set_textures' array when CRTMaterial::isTexture(), else -1 */
+/* R/CRTTexture*.h: type 0 albedo (color_a), 1 edges (color_a = edge colour, color_b = inner colour, scalar = edge width; evaluated
+ * on the hit's barycentrics), 2 checker (color_a / color_b, scalar = square size), 3 bitmap (pixels: height x width x channels
+ * bytes, channels >= 3, nearest texel, v flipped); 2 and 3 are evaluated on the mesh uvs interpolated at the hit */
+enum { CRT_TEX_ALBEDO = 0, CRT_TEX_EDGES = 1, CRT_TEX_CHECKER = 2, CRT_TEX_BITMAP = 3 };
+typedef struct crt_texture { uint32_t type; float color_a[3]; float color_b[3]; float scalar; const uint8_t* pixels; uint32_t width, height, channels; } crt_texture;
 
 /* 64-byte BVH node and 48-byte leaf-ordered triangle/shading records as they sit in HBM */
 typedef struct crt_bvh_node {
@@ -81,6 +88,7 @@ typedef struct crt_bvh_node4 {
 } crt_bvh_node4;
 typedef struct crt_bvh_tri { float v0[3]; uint32_t inst; float e1[3]; uint32_t prim; float e2[3]; uint32_t gid; } crt_bvh_tri;
 typedef struct crt_bvh_shade { float n0[3], n1[3], n2[3]; uint32_t material; uint32_t pad[2]; } crt_bvh_shade;
+typedef struct crt_bvh_uv { float uv0[2], uv1[2], uv2[2]; } crt_bvh_uv; /* 24 B, leaf order, only when some mesh has uvs */
 
 typedef struct crt_frame_stats {
     double kernel_ms;        /* HIP-event time of the render kernel(s) on the context's stream */
@@ -111,6 +119,11 @@ uint32_t crt_abi_version(void);
 int crt_upload_scene(crt_ctx* ctx, const crt_mesh_view* meshes, uint32_t n_meshes,
                      const crt_light* lights, uint32_t n_lights,
                      const crt_material* materials, uint32_t n_materials);
+
+/* textures the materials refer to by index (CRTScene::getTextures / getTextureByName, R/CRTScene.h:32-34); copied, pixels
+ * included; may be called before or after crt_upload_scene. The reference parses them but its renderer never samples
+ * them; here they drive the albedo of modes 100 and 200 */
+int crt_set_textures(crt_ctx* ctx, const crt_texture* textures, uint32_t n_textures);
 
 /* updateCameraCB (R/DXRTRenderer.cpp:248-270): position + 3x3 row-major rotation, dirWorld = R * dirCam */
 int crt_set_camera(crt_ctx* ctx, const float pos[3], const float rot3x3_rowmajor[9]);
@@ -169,6 +182,8 @@ int crt_synchronize(crt_ctx* ctx);
 /* BVH introspection (tests, tooling): sizes, then copies of the host-side arrays uploaded to HBM */
 int crt_bvh_info(const crt_ctx* ctx, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* max_depth);
 int crt_bvh_export(const crt_ctx* ctx, crt_bvh_node* nodes, crt_bvh_tri* tris, crt_bvh_shade* shade);
+/* per-triangle texture coordinates in leaf order; *has_uvs = 0 (and nothing copied) when no mesh carried uvs */
+int crt_bvh_export_uv(const crt_ctx* ctx, crt_bvh_uv* uvs, int* has_uvs);
 /* wall time of the last crt_upload_scene (flatten + build + collapse + upload) and, with option "gpu_build" = 1 (LBVH
  * built by HIP kernels instead of the host SAH builder: faster build, slower traversal), the device time of the build kernels */
 int crt_build_stats(const crt_ctx* ctx, double* upload_ms, double* device_build_ms);
@@ -211,6 +226,13 @@ int crt_scene_light(const crt_scene* s, uint32_t i, crt_light* out);
 uint32_t crt_scene_material_count(const crt_scene* s);                           /* getMaterials() */
 int crt_scene_material(const crt_scene* s, uint32_t i, crt_material* out);
 uint32_t crt_scene_texture_count(const crt_scene* s);                            /* getTextures().size() */
+/* CRTTexture::getColor(u, v) of texture i (R/CRTTexture*.cpp), evaluated on the host */
+int crt_scene_texture_color(const crt_scene* s, uint32_t i, float u, float v, float out_rgb[3]);
+/* programmatic textures: type = "albedo" | "edges" | "checker" | "bitmap" (file_path: binary PPM); a material refers to one by name */
+int crt_scene_add_texture(crt_scene* s, const char* name, const char* type, const float color_a[3], const float color_b[3], float scalar,
+                          const char* file_path);
+int crt_scene_set_material_texture(crt_scene* s, uint32_t material, const char* texture_name);
+int crt_scene_set_mesh_uvs(crt_scene* s, uint32_t mesh, const float* uvs /* n_vertices * 3 */);
 int crt_scene_settings(const crt_scene* s, uint32_t* width, uint32_t* height, float background_rgb[3]); /* getSettings() */
 
 /* CRTCamera (R/CRTCamera.h:5-32, .cpp:9-130) on the scene's camera */

@@ -120,6 +120,9 @@ struct oracle_scene {
     uint32_t n_lights;
     oracle_material* mats;
     uint32_t n_mats;
+    oracle_uv* uvs;       /* leaf order, NULL when no mesh has uvs */
+    oracle_texture* tex;  /* owns copies of the pixel buffers */
+    uint32_t n_tex;
 };
 
 typedef struct { float mn[3], mx[3]; } aabb;
@@ -483,6 +486,9 @@ oracle_scene* oracle_scene_create_ex(const oracle_mesh* meshes, uint32_t n_meshe
     /* flatten in input order: gid = running triangle ordinal over meshes */
     oracle_tri* in_tri = (oracle_tri*)malloc(sizeof(oracle_tri) * (n ? n : 1));
     oracle_shade* in_sh = (oracle_shade*)malloc(sizeof(oracle_shade) * (n ? n : 1));
+    int any_uv = 0;
+    for (uint32_t m = 0; m < n_meshes; m++) any_uv |= meshes[m].uvs != NULL && meshes[m].n_triangles > 0;
+    oracle_uv* in_uv = any_uv ? (oracle_uv*)calloc(n ? n : 1, sizeof(oracle_uv)) : NULL;
     aabb* pbox = (aabb*)malloc(sizeof(aabb) * (n ? n : 1));
     float* pcent = (float*)malloc(sizeof(float) * 3 * (n ? n : 1));
     uint32_t g = 0;
@@ -510,6 +516,11 @@ oracle_scene* oracle_scene_create_ex(const oracle_mesh* meshes, uint32_t n_meshe
                 memcpy(S->n0, &M->normals[3 * i0], 12);
                 memcpy(S->n1, &M->normals[3 * i1], 12);
                 memcpy(S->n2, &M->normals[3 * i2], 12);
+            }
+            if (in_uv && M->uvs) {
+                memcpy(in_uv[g].uv0, &M->uvs[3 * i0], 8);
+                memcpy(in_uv[g].uv1, &M->uvs[3 * i1], 8);
+                memcpy(in_uv[g].uv2, &M->uvs[3 * i2], 8);
             }
         }
     }
@@ -557,6 +568,11 @@ oracle_scene* oracle_scene_create_ex(const oracle_mesh* meshes, uint32_t n_meshe
     s->tris = (oracle_tri*)malloc(sizeof(oracle_tri) * (n ? n : 1));
     s->shade = (oracle_shade*)malloc(sizeof(oracle_shade) * (n ? n : 1));
     for (uint32_t i = 0; i < n; i++) { s->tris[i] = in_tri[B.order[i]]; s->shade[i] = in_sh[B.order[i]]; }
+    if (in_uv) {
+        s->uvs = (oracle_uv*)malloc(sizeof(oracle_uv) * (n ? n : 1));
+        for (uint32_t i = 0; i < n; i++) s->uvs[i] = in_uv[B.order[i]];
+        free(in_uv);
+    }
     free(B.order); free(B.tmp); free(in_tri); free(in_sh); free(pbox); free(pcent);
     return s;
 }
@@ -564,7 +580,9 @@ oracle_scene* oracle_scene_create_ex(const oracle_mesh* meshes, uint32_t n_meshe
 void oracle_scene_destroy(oracle_scene* s)
 {
     if (!s) return;
-    free(s->nodes); free(s->nodes4); free(s->tris); free(s->shade); free(s->lights); free(s->mats);
+    free(s->nodes); free(s->nodes4); free(s->tris); free(s->shade); free(s->lights); free(s->mats); free(s->uvs);
+    for (uint32_t i = 0; i < s->n_tex; i++) free((void*)s->tex[i].pixels);
+    free(s->tex);
     free(s);
 }
 
@@ -572,7 +590,8 @@ int oracle_scene_set_bvh(oracle_scene* s, const oracle_node* nodes, uint32_t n_n
                          const oracle_tri* tris, const oracle_shade* shade, uint32_t n_tris)
 {
     if (!s) return 1;
-    free(s->nodes); free(s->tris); free(s->shade);
+    free(s->nodes); free(s->tris); free(s->shade); free(s->uvs);
+    s->uvs = NULL;
     s->nodes = (oracle_node*)malloc(sizeof(oracle_node) * (n_nodes ? n_nodes : 1));
     s->tris = (oracle_tri*)malloc(sizeof(oracle_tri) * (n_tris ? n_tris : 1));
     s->shade = (oracle_shade*)calloc(n_tris ? n_tris : 1, sizeof(oracle_shade));
@@ -582,6 +601,58 @@ int oracle_scene_set_bvh(oracle_scene* s, const oracle_node* nodes, uint32_t n_n
     s->n_nodes = n_nodes; s->n_tris = n_tris;
     build_wide(s);
     return 0;
+}
+
+int oracle_scene_set_textures(oracle_scene* s, const oracle_texture* tex, uint32_t n)
+{
+    if (!s || (!tex && n)) return 1;
+    for (uint32_t i = 0; i < s->n_tex; i++) free((void*)s->tex[i].pixels);
+    free(s->tex);
+    s->tex = (oracle_texture*)calloc(n ? n : 1, sizeof(oracle_texture));
+    s->n_tex = n;
+    for (uint32_t i = 0; i < n; i++) {
+        s->tex[i] = tex[i];
+        s->tex[i].pixels = NULL;
+        if (tex[i].type == 3u && tex[i].pixels && tex[i].width && tex[i].height && tex[i].channels) {
+            size_t bytes = (size_t)tex[i].width * tex[i].height * tex[i].channels;
+            uint8_t* copy = (uint8_t*)malloc(bytes);
+            memcpy(copy, tex[i].pixels, bytes);
+            s->tex[i].pixels = copy;
+        }
+    }
+    return 0;
+}
+const oracle_uv* oracle_scene_uvs(const oracle_scene* s) { return s->uvs; }
+
+/* R/CRTTexture*.cpp getColor, operation for operation.  Bitmaps need >= 3 channels here (the reference reads the green
+ * byte of 1-channel images from the next pixel: not reproduced). */
+static v3 texture_color(const oracle_texture* t, float u, float v)
+{
+    const v3 A = v3_make(t->color_a[0], t->color_a[1], t->color_a[2]);
+    const v3 Bc = v3_make(t->color_b[0], t->color_b[1], t->color_b[2]);
+    if (t->type == 1u) /* R/CRTTextureEdges.cpp:9-15 */
+        return (u < t->scalar || v < t->scalar || (1.0f - u - v) < t->scalar) ? A : Bc;
+    if (t->type == 2u) { /* R/CRTTextureChecker.cpp:9-20 */
+        int width = (int)(1.0f / t->scalar);
+        int u2 = (int)floorf(u * (float)width);
+        int v2 = (int)floorf(v * (float)width);
+        return ((u2 + v2) % 2 == 0) ? A : Bc;
+    }
+    if (t->type == 3u) { /* R/CRTTextureBitmap.cpp:12-36 */
+        if (!t->pixels || t->channels < 3u) return v3_make(0.0f, 0.0f, 0.0f);
+        u = fminf(fmaxf(u, 0.0f), 1.0f);
+        v = fminf(fmaxf(v, 0.0f), 1.0f);
+        int row = (int)((1.0f - v) * (float)((int)t->height - 1));
+        int col = (int)(u * (float)((int)t->width - 1));
+        size_t index = ((size_t)row * t->width + (size_t)col) * t->channels;
+        return v3_make((float)t->pixels[index] / 255.0f, (float)t->pixels[index + 1] / 255.0f, (float)t->pixels[index + 2] / 255.0f);
+    }
+    return A; /* albedo texture, R/CRTTextureAlbedo.cpp */
+}
+void oracle_texture_color(const oracle_texture* t, float u, float v, float out_rgb[3])
+{
+    v3 c = texture_color(t, u, v);
+    out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z;
 }
 
 uint32_t oracle_scene_node_count(const oracle_scene* s) { return s->n_nodes; }
@@ -999,6 +1070,22 @@ static void surface_at(const oracle_scene* s, const ray* r, const hit_rec* h, su
         smooth = M->smooth != 0;
         sf->mtype = M->type;
         sf->ior = M->ior;
+        if (M->texture >= 0 && (uint32_t)M->texture < s->n_tex) {
+            /* CRTMaterial::isTexture: the albedo comes from the texture. Edges textures are functions of the hit's
+             * barycentrics; the others of the mesh uvs interpolated at the hit (0,0 when the mesh has none). */
+            const oracle_texture* tx = &s->tex[M->texture];
+            float tu = h->u, tv = h->v;
+            if (tx->type != 1u) {
+                tu = 0.0f; tv = 0.0f;
+                if (s->uvs) {
+                    const oracle_uv* U = &s->uvs[h->tri];
+                    const float w = 1.0f - h->u - h->v;
+                    tu = fmaf(U->uv2[0], h->v, fmaf(U->uv1[0], h->u, U->uv0[0] * w));
+                    tv = fmaf(U->uv2[1], h->v, fmaf(U->uv1[1], h->u, U->uv0[1] * w));
+                }
+            }
+            sf->albedo = texture_color(tx, tu, tv);
+        }
     }
     v3 N = v3_cross(v3_make(T->e1[0], T->e1[1], T->e1[2]), v3_make(T->e2[0], T->e2[1], T->e2[2]));
     if (smooth) {

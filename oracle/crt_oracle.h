@@ -65,17 +65,25 @@ typedef struct oracle_shade {
     uint32_t material; uint32_t pad[2];
 } oracle_shade;
 
+/* 24-byte per-triangle texture coordinates, same order as oracle_tri (only when some mesh has uvs) */
+typedef struct oracle_uv { float uv0[2], uv1[2], uv2[2]; } oracle_uv;
+
 typedef struct oracle_mesh {
     const float* xyz;       /* n_vertices * 3 */
     const uint32_t* idx;    /* n_triangles * 3 */
     const float* normals;   /* n_vertices * 3, or NULL (then flat shading) */
+    const float* uvs;       /* n_vertices * 3 (u, v, unused: the .crtscene "uvs" layout), or NULL */
     uint32_t n_vertices;
     uint32_t n_triangles;
     int32_t material_index;
 } oracle_mesh;
 
 typedef struct oracle_light { float pos[3]; float intensity; } oracle_light;
-typedef struct oracle_material { float albedo[3]; uint32_t type; uint32_t smooth; float ior; } oracle_material;
+typedef struct oracle_material { float albedo[3]; uint32_t type; uint32_t smooth; float ior; int32_t texture; /* -1 none */ } oracle_material;
+/* R/CRTTexture*.cpp: type 0 albedo (color_a), 1 edges (color_a edge, color_b inner, scalar = edge width; sampled with the
+ * hit's barycentrics), 2 checker (color_a/b, scalar = square size), 3 bitmap (pixels, nearest texel, v flipped); checker and
+ * bitmap are sampled with the interpolated mesh uvs */
+typedef struct oracle_texture { uint32_t type; float color_a[3]; float color_b[3]; float scalar; const uint8_t* pixels; uint32_t width, height, channels; } oracle_texture;
 
 typedef struct oracle_stats {
     uint64_t rays_primary, rays_shadow; /* closest-hit rays (camera + bounce) / any-hit shadow rays */
@@ -100,6 +108,11 @@ oracle_scene* oracle_scene_create_ex(const oracle_mesh* meshes, uint32_t n_meshe
 int oracle_scene_set_bvh(oracle_scene* s, const oracle_node* nodes, uint32_t n_nodes,
                          const oracle_tri* tris, const oracle_shade* shade, uint32_t n_tris);
 
+/* textures referenced by oracle_material.texture (copied, pixels too) */
+int oracle_scene_set_textures(oracle_scene* s, const oracle_texture* tex, uint32_t n);
+const oracle_uv* oracle_scene_uvs(const oracle_scene* s); /* NULL when no mesh has uvs */
+/* R/CRTTexture*.cpp getColor restated (known answers: tests/golden/texture_known_answers.json) */
+void oracle_texture_color(const oracle_texture* t, float u, float v, float out_rgb[3]);
 uint32_t oracle_scene_node_count(const oracle_scene* s);
 uint32_t oracle_scene_node4_count(const oracle_scene* s);
 const oracle_node4* oracle_scene_nodes4(const oracle_scene* s);

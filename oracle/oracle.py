@@ -28,7 +28,7 @@ assert NODE4_DTYPE.itemsize == 128 and NODE_DTYPE.itemsize == 64 and TRI_DTYPE.i
 
 
 class _Mesh(C.Structure):
-    _fields_ = [("xyz", C.c_void_p), ("idx", C.c_void_p), ("normals", C.c_void_p),
+    _fields_ = [("xyz", C.c_void_p), ("idx", C.c_void_p), ("normals", C.c_void_p), ("uvs", C.c_void_p),
                 ("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32), ("material_index", C.c_int32)]
 
 
@@ -37,7 +37,32 @@ class _Light(C.Structure):
 
 
 class _Material(C.Structure):
-    _fields_ = [("albedo", C.c_float * 3), ("type", C.c_uint32), ("smooth", C.c_uint32), ("ior", C.c_float)]
+    _fields_ = [("albedo", C.c_float * 3), ("type", C.c_uint32), ("smooth", C.c_uint32), ("ior", C.c_float), ("texture", C.c_int32)]
+
+
+class _Texture(C.Structure):
+    _fields_ = [("type", C.c_uint32), ("color_a", C.c_float * 3), ("color_b", C.c_float * 3), ("scalar", C.c_float),
+                ("pixels", C.c_void_p), ("width", C.c_uint32), ("height", C.c_uint32), ("channels", C.c_uint32)]
+
+
+TEXTURE_TYPES = {"albedo": 0, "edges": 1, "checker": 2, "bitmap": 3}
+UV_DTYPE = np.dtype([("uv0", "f4", 2), ("uv1", "f4", 2), ("uv2", "f4", 2)])
+
+
+def make_texture(t, keep):
+    """t: dict {type: albedo|edges|checker|bitmap, color_a, color_b, scalar, pixels (H,W,C uint8)}"""
+    x = _Texture()
+    x.type = TEXTURE_TYPES[t["type"]]
+    x.color_a = (C.c_float * 3)(*[float(c) for c in t.get("color_a", (0, 0, 0))])
+    x.color_b = (C.c_float * 3)(*[float(c) for c in t.get("color_b", (0, 0, 0))])
+    x.scalar = float(t.get("scalar", 0.0))
+    px = t.get("pixels")
+    if px is not None:
+        px = np.ascontiguousarray(px, dtype=np.uint8)
+        keep.append(px)
+        x.pixels = px.ctypes.data
+        x.height, x.width, x.channels = px.shape
+    return x
 
 
 class Stats(C.Structure):
@@ -93,6 +118,10 @@ def lib():
         L.oracle_intersect_tri.restype = C.c_int
         L.oracle_intersect_tri.argtypes = [C.c_void_p] * 5 + [C.c_float, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.oracle_max_threads.restype = C.c_int
+        L.oracle_scene_set_textures.argtypes = [C.c_void_p, C.c_void_p, C.c_uint32]
+        L.oracle_scene_uvs.restype = C.c_void_p
+        L.oracle_scene_uvs.argtypes = [C.c_void_p]
+        L.oracle_texture_color.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.oracle_set_path_params.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
         L.oracle_set_cost_outputs.argtypes = [C.c_void_p] * 4
         L.oracle_set_stack_output.argtypes = [C.c_void_p]
@@ -111,8 +140,9 @@ class OracleScene:
     """meshes: list of dicts {vertices (N,3) f32, triangles (M,3) u32, normals (N,3) f32|None, material_index}
     lights: list of (pos3, intensity); materials: list of dicts {albedo, type, smooth_shading, ior}."""
 
-    def __init__(self, meshes, lights=(), materials=(), build_mode=0):
-        """build_mode 0 = binned SAH, 1 = LBVH (spec of the GPU builder)"""
+    def __init__(self, meshes, lights=(), materials=(), build_mode=0, textures=()):
+        """build_mode 0 = binned SAH, 1 = LBVH (spec of the GPU builder); textures: list of dicts (make_texture),
+        referenced by materials through {"texture": index}"""
         L = lib()
         self._keep = []
         marr = (_Mesh * max(1, len(meshes)))()
@@ -123,10 +153,15 @@ class OracleScene:
             if nrm is not None:
                 nrm = _f32(nrm).reshape(-1, 3)
                 assert nrm.shape == v.shape
-            self._keep += [v, t, nrm]
+            uv = m.get("uvs")
+            if uv is not None:
+                uv = _f32(uv).reshape(-1, 3)
+                assert uv.shape == v.shape
+            self._keep += [v, t, nrm, uv]
             marr[i].xyz = v.ctypes.data
             marr[i].idx = t.ctypes.data
             marr[i].normals = nrm.ctypes.data if nrm is not None else None
+            marr[i].uvs = uv.ctypes.data if uv is not None else None
             marr[i].n_vertices = v.shape[0]
             marr[i].n_triangles = t.shape[0]
             marr[i].material_index = int(m.get("material_index", 0))
@@ -140,9 +175,13 @@ class OracleScene:
             matarr[i].type = int(m.get("type", 1))
             matarr[i].smooth = int(bool(m.get("smooth_shading", False)))
             matarr[i].ior = float(m.get("ior", 1.0))
+            matarr[i].texture = int(m.get("texture", -1))
         self.h = L.oracle_scene_create_ex(marr, len(meshes), larr, len(lights), matarr, len(materials), int(build_mode))
         if not self.h:
             raise RuntimeError("oracle_scene_create failed")
+        if textures:
+            tarr = (_Texture * len(textures))(*[make_texture(t, self._keep) for t in textures])
+            assert L.oracle_scene_set_textures(self.h, tarr, len(textures)) == 0
 
     def close(self):
         if self.h:
@@ -197,6 +236,12 @@ class OracleScene:
 
     def shade(self):
         return self._view("oracle_scene_shade", SHADE_DTYPE, self.n_tris)
+
+    def uvs(self):
+        p = lib().oracle_scene_uvs(self.h)
+        if not p or self.n_tris == 0:
+            return None
+        return np.frombuffer((C.c_char * (self.n_tris * 24)).from_address(p), dtype=UV_DTYPE).copy()
 
     def set_bvh(self, nodes, tris, shade=None):
         nodes = np.ascontiguousarray(nodes)
@@ -278,6 +323,14 @@ def intersect_tri(o, d, v0, v1, v2, tmin=0.001, tmax=10000.0):
 def set_path_params(spp=4, max_bounces=3, seed=1234):
     """mode 200 parameters (process-wide in the oracle)"""
     lib().oracle_set_path_params(int(spp), int(max_bounces), int(seed))
+
+
+def texture_color(t, u, v):
+    keep = []
+    x = make_texture(t, keep)
+    out = np.zeros(3, dtype=np.float32)
+    lib().oracle_texture_color(C.byref(x), float(np.float32(u)), float(np.float32(v)), out.ctypes.data)
+    return out
 
 
 def max_threads():

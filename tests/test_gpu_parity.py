@@ -236,13 +236,13 @@ def test_scheduling_knobs_never_change_results(pkg, oracle, scenes, dragon, rend
 
 def _compare_path(pkg, oracle, renderer, sc, w, h, spp, bounces, seed, miss=(0.0, 0.0, 0.0)):
     cam = sc["camera"]
-    renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+    renderer.upload(sc["meshes"], sc["lights"], sc["materials"], sc.get("textures"))
     renderer.set_camera(cam["position"], cam["matrix"])
     renderer.set_miss_color(miss)
     renderer.change_shading_mode(pkg.MODE_PATH)
     renderer.set_path_params(spp, bounces, seed)
     renderer.set_counting(True)
-    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"], textures=sc.get("textures") or ())
     oracle.set_path_params(spp, bounces, seed)
     try:
         got = renderer.render_frame(w, h)
@@ -453,3 +453,40 @@ def test_gpu_bvh_build_matches_its_spec_and_renders_identically(pkg, oracle, sce
         assert r.build_stats()["device_build_ms"] == 0.0
     finally:
         r.close()
+
+
+def test_textured_scene(pkg, oracle, scenes, renderer):
+    """the reference's four texture kinds sampled on the device (diffuse hits of modes 100
+    and 200), uvs carried through the BVH reorder; identical to the oracle, whose texture functions are pinned by
+    tests/golden/texture_known_answers.json."""
+    sc = scenes.textured_cornell()
+    cam = sc["camera"]
+    w, h = 320, 240
+    renderer.upload(sc["meshes"], sc["lights"], sc["materials"], sc["textures"])
+    renderer.set_camera(cam["position"], cam["matrix"])
+    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"], textures=sc["textures"])
+    uv = renderer.bvh_export_uv()
+    assert uv is not None and uv.tobytes() == O.uvs().tobytes()
+    renderer.change_shading_mode(100)
+    got = renderer.render_frame(w, h)
+    ref = O.render(cam["position"], cam["matrix"], 100, w, h)
+    np.testing.assert_array_equal(got["hit_prim"], ref["hit_prim"])
+    np.testing.assert_array_equal(got["rgba8"], ref["rgba8"])
+    assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True)
+    # the textures really are in the picture: the same scene without them renders differently, and many distinct colours appear
+    plain = renderer.render_frame(w, h)["rgba8"].copy()
+    renderer.set_textures([])
+    assert not np.array_equal(renderer.render_frame(w, h)["rgba8"], plain)
+    renderer.set_textures(sc["textures"])
+    assert len(np.unique(plain.reshape(-1, 4), axis=0)) > 500
+    _compare_path(pkg, oracle, renderer, sc, w, h, spp=4, bounces=4, seed=11)
+    # a texture index past the table, and a material that names a texture on a scene without uvs, fall back to the plain albedo
+    sc2 = scenes.cornell_box()
+    sc2["materials"][0]["texture"] = 0
+    renderer.upload(sc2["meshes"], sc2["lights"], sc2["materials"], [sc["textures"][0]])
+    assert renderer.bvh_export_uv() is None
+    renderer.change_shading_mode(100)
+    O2 = oracle.OracleScene(sc2["meshes"], sc2["lights"], sc2["materials"], textures=[sc["textures"][0]])
+    got = renderer.render_frame(64, 64)
+    ref = O2.render(cam["position"], cam["matrix"], 100, 64, 64)
+    np.testing.assert_array_equal(got["rgba8"], ref["rgba8"])

@@ -200,3 +200,69 @@ def test_binary_cache_rejects_damaged_files(pkg, scene, tmp_path):
         pkg.Scene(str(q))
     with pytest.raises(pkg.CrtError):
         scene.save(str(tmp_path / "no_such_dir" / "x.crtbin"))
+
+
+# ----------------------------------------------------------------------------------------- textures (row f3)
+def _texture_goldens(golden_dir):
+    g = json.load(open(os.path.join(golden_dir, "texture_known_answers.json")))
+    raw = open(os.path.join(golden_dir, "tex7x5.ppm"), "rb").read()
+    img = np.frombuffer(raw[raw.index(b"255\n") + 4:], dtype=np.uint8).reshape(5, 7, 3)
+    return g, img
+
+
+def test_texture_classes_match_the_reference(pkg, oracle, golden_dir):
+    """CRTTexture{Albedo,Edges,Checker,Bitmap}::getColor (R/CRTTexture*.cpp) on a 21x21 grid of (u,v): known answers
+    produced by the reference's own classes (its bitmap one decoding tests/golden/tex7x5.ppm through its vendored
+    stb_image); the host scene layer AND the oracle's restatement must reproduce every value exactly."""
+    g, img = _texture_goldens(golden_dir)
+    s = pkg.Scene()
+    s.add_texture("a", "albedo", g["params"]["albedo"])
+    e = g["params"]["edges"]
+    s.add_texture("e", "edges", e["edge_color"], e["inner_color"], e["edge_width"])
+    c = g["params"]["checker"]
+    s.add_texture("c", "checker", c["color_A"], c["color_B"], c["square_size"])
+    s.add_texture("b", "bitmap", file_path=os.path.join(golden_dir, "tex7x5.ppm"))
+    assert s.texture_count == 4
+    odesc = {"albedo": {"type": "albedo", "color_a": g["params"]["albedo"]},
+             "edges": {"type": "edges", "color_a": e["edge_color"], "color_b": e["inner_color"], "scalar": e["edge_width"]},
+             "checker": {"type": "checker", "color_a": c["color_A"], "color_b": c["color_B"], "scalar": c["square_size"]},
+             "bitmap": {"type": "bitmap", "pixels": img}}
+    for i, name in enumerate(("albedo", "edges", "checker", "bitmap")):
+        assert len(g[name]) > 200
+        for u, v, r, gg, b in g[name]:
+            exp = np.float32([r, gg, b])
+            np.testing.assert_array_equal(s.texture_color(i, u, v), exp, err_msg="%s host (%g,%g)" % (name, u, v))
+            np.testing.assert_array_equal(oracle.texture_color(odesc[name], u, v), exp, err_msg="%s oracle (%g,%g)" % (name, u, v))
+
+
+def test_textured_scene_file(pkg, tmp_path, golden_dir):
+    """a .crtscene with uvs, a texture-named albedo and all four texture kinds (the keys R/CRTSceneParser.cpp:83-306 reads)"""
+    import shutil
+    shutil.copy(os.path.join(golden_dir, "tex7x5.ppm"), tmp_path / "img.ppm")
+    p = tmp_path / "tex.crtscene"
+    p.write_text(json.dumps({
+        "objects": [{"material_index": 0, "vertices": [0, 0, 0, 1, 0, 0, 0, 1, 0], "triangles": [0, 1, 2], "uvs": [0, 0, 0, 1, 0, 0, 0, 1, 0]}],
+        "materials": [{"type": "diffuse", "albedo": "chk", "smooth_shading": False}, {"type": "diffuse", "albedo": "missing_name"}],
+        "textures": [{"name": "alb", "type": "albedo", "albedo": [0.1, 0.2, 0.3]},
+                     {"name": "edg", "type": "edges", "edge_color": [1, 1, 1], "inner_color": [0, 0, 0], "edge_width": 0.05},
+                     {"name": "chk", "type": "checker", "color_A": [1, 0, 0], "color_B": [0, 1, 0], "square_size": 0.25},
+                     {"name": "pic", "type": "bitmap", "file_path": "img.ppm"}]}))
+    s = pkg.Scene(str(p))
+    assert s.texture_count == 4
+    mats = s.materials()
+    assert mats[0]["texture"] == 2 and mats[1]["texture"] == -1  # by name; unknown names resolve to none
+    np.testing.assert_array_equal(s.mesh(0)["uvs"], np.float32([[0, 0, 0], [1, 0, 0], [0, 1, 0]]))
+    np.testing.assert_array_equal(s.texture_color(2, 0.3, 0.1), np.float32([0, 1, 0]))
+    np.testing.assert_array_equal(s.texture_color(0, 0.9, 0.9), np.float32([0.1, 0.2, 0.3]))
+    assert np.all(s.texture_color(3, 0.5, 0.5) > 0)
+    # survives the binary cache (bitmap re-read from its path next to the cache file)
+    s.save(str(tmp_path / "tex.crtbin"))
+    b = pkg.Scene(str(tmp_path / "tex.crtbin"))
+    assert b.texture_count == 4 and b.materials()[0]["texture"] == 2
+    np.testing.assert_array_equal(b.texture_color(3, 0.5, 0.5), s.texture_color(3, 0.5, 0.5))
+    np.testing.assert_array_equal(b.mesh(0)["uvs"], s.mesh(0)["uvs"])
+    # a bitmap that is not a binary PPM/PGM is a load error, not a crash (the reference never checks stbi_load's result)
+    (tmp_path / "img.ppm").write_bytes(b"\\x89PNG....")
+    with pytest.raises(pkg.CrtError) as e:
+        pkg.Scene(str(p))
+    assert "PPM" in str(e.value)
