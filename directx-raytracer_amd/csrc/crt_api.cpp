@@ -61,19 +61,24 @@ struct crt_ctx {
     uint32_t tuneXcdGroup = 16;
     uint32_t tuneBoostUnits = 512;
     uint32_t debugSkipUnits = 0;
+    bool sortInline = false;
     bool adaptiveOrder = true;     // launch the work units of frame N+1 in descending order of their cost in frame N
-    uint32_t* dUnitCost[2] = { nullptr, nullptr };
-    uint32_t* dUnitOrder[2] = { nullptr, nullptr };
+    // Per-frame scratch lives in a ring of kRing slots: frame f uses slot f % kRing and first waits (on the GPU, never on
+    // the host) for the frame that used the slot before it, so up to kRing frames issued on different streams run
+    // concurrently without sharing a spill arena or a cost/order buffer.
+    static constexpr int kRing = 4;
+    uint32_t* dUnitCost[kRing] = {};
+    uint32_t* dUnitOrder[kRing] = {};
     uint32_t unitCapacity = 0;
-    uint64_t orderKey[2] = { 0, 0 }; // frame geometry each stored order belongs to; 0 = none
-    bool sortPending[2] = { false, false };
+    uint64_t orderKey[kRing] = {};   // frame geometry each stored order belongs to; 0 = none
+    bool sortPending[kRing] = {};    // evSort[slot] recorded (a sort of this slot's costs was issued)
+    bool renderPending[kRing] = {};  // evRender[slot] recorded
     uint32_t frameSerial = 0;
-    hipStream_t sideStream = nullptr; // runs the sort of frame k concurrently with the render of frame k+1
-    hipEvent_t evRender[2] = { nullptr, nullptr }, evSort[2] = { nullptr, nullptr };
+    hipStream_t sideStream = nullptr; // sorts the costs of frame f while later frames render
+    hipEvent_t evRender[kRing] = {}, evSort[kRing] = {};
     unsigned long long* dCounters = nullptr;
-    int* dSpill[2] = { nullptr, nullptr }; // traversal-stack spill arenas (render_kernels.hip Stack); two, because two
-    size_t spillBytes[2] = { 0, 0 };       // consecutive frames may run concurrently on alternating streams
-    uint32_t spillTurn = 0;
+    int* dSpill[kRing] = {};          // traversal-stack spill arenas (render_kernels.hip Stack), one per ring slot
+    size_t spillBytes[kRing] = {};
     unsigned long long* dTimeline = nullptr; // diagnostic: 3 words per workgroup, counting variant only
     size_t timelineWords = 0;
     bool wantTimeline = false;
@@ -190,35 +195,35 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         HIP_TRY(c, hipMemsetAsync(c->dTimeline, 0, c->timelineWords * sizeof(unsigned long long), c->stream));
         p.timeline = c->dTimeline;
     }
+    const uint32_t slot = c->frameSerial++ % crt_ctx::kRing;
     {
         // deepest stack a ray can build: three pending siblings per wide level; what does not fit the LDS part spills
         const uint32_t deepest = 3u * c->bvh.depth4 + 1u;
         p.spill_stride = deepest > p.stack_entries ? deepest - p.stack_entries : 1u;
         const size_t need = static_cast<size_t>(crt::renderUnitCount(p)) * 64u * p.spill_stride * sizeof(int);
-        const uint32_t turn = c->spillTurn++ & 1u;
-        if (c->spillBytes[turn] < need) {
+        if (c->spillBytes[slot] < need) {
             HIP_TRY(c, hipDeviceSynchronize());
-            if (c->dSpill[turn]) (void)hipFree(c->dSpill[turn]);
-            c->dSpill[turn] = nullptr;
-            c->spillBytes[turn] = 0;
-            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dSpill[turn]), need));
-            c->spillBytes[turn] = need;
+            if (c->dSpill[slot]) (void)hipFree(c->dSpill[slot]);
+            c->dSpill[slot] = nullptr;
+            c->spillBytes[slot] = 0;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dSpill[slot]), need));
+            c->spillBytes[slot] = need;
         }
-        p.spill = c->dSpill[turn];
+        p.spill = c->dSpill[slot];
     }
-    // Cost feedback: the lifetimes frame k's wavefronts report are sorted on a side stream WHILE frame k+1 renders and
-    // order the launch of frame k+2 (two alternating buffer sets), so the sort never sits on the frame's critical path.
-    // Hint only: a stale or missing order changes speed, never results.
+    // Cost feedback: the lifetimes frame f's wavefronts report are sorted on a side stream while the next frames render and
+    // order the launch of frame f + kRing (same ring slot), so neither the sort nor the dependency on an earlier frame
+    // sits on a frame's critical path and kRing frames can be in flight.  Hint only: a stale or missing order changes
+    // speed, never results.
     const uint32_t nUnits = crt::renderUnitCount(p);
     const uint64_t key = (static_cast<uint64_t>(p.width) << 40) ^ (static_cast<uint64_t>(p.height) << 20) ^
                          (static_cast<uint64_t>(p.n_ranks) << 8) ^ p.rank ^ (static_cast<uint64_t>(c->sceneSerial) << 52) ^ 1ull;
-    const uint32_t slot = c->frameSerial & 1u;
     bool feedback = false;
     if (c->adaptiveOrder && nUnits) {
         if (c->unitCapacity < nUnits) {
             HIP_TRY(c, hipStreamSynchronize(c->sideStream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < crt_ctx::kRing; i++) {
                 if (c->dUnitCost[i]) (void)hipFree(c->dUnitCost[i]);
                 if (c->dUnitOrder[i]) (void)hipFree(c->dUnitOrder[i]);
                 c->dUnitCost[i] = c->dUnitOrder[i] = nullptr;
@@ -226,31 +231,35 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
                 c->sortPending[i] = false;
             }
             c->unitCapacity = 0;
-            for (int i = 0; i < 2; i++) {
+            for (int i = 0; i < crt_ctx::kRing; i++) {
                 HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dUnitCost[i]), sizeof(uint32_t) * nUnits));
                 HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dUnitOrder[i]), sizeof(uint32_t) * nUnits));
             }
             c->unitCapacity = nUnits;
         }
-        // the sort of frame k-2 read cost[slot] and wrote order[slot]: it must be done before this frame touches either
-        if (c->sortPending[slot]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evSort[slot], 0));
         p.unit_cost = c->dUnitCost[slot];
         p.unit_order = c->orderKey[slot] == key ? c->dUnitOrder[slot] : nullptr;
         feedback = true;
     }
+    // the previous user of this slot (frame f - kRing, possibly on another stream) and the sort of its costs must be done
+    // before this frame touches the slot's spill arena, cost or order buffer
+    if (c->sortPending[slot]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evSort[slot], 0));
+    if (c->renderPending[slot]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evRender[slot], 0));
+    c->sortPending[slot] = false;
     if (stats) HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     const int rc = crt::launchRender(p, counting, c->stream);
     if (rc != 0) return fail(c, CRT_EHIP, "render kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
     if (stats) HIP_TRY(c, hipEventRecord(c->evStop, c->stream)); // kernel_ms = the render kernel alone
+    HIP_TRY(c, hipEventRecord(c->evRender[slot], c->stream));
+    c->renderPending[slot] = true;
     if (feedback) {
-        HIP_TRY(c, hipEventRecord(c->evRender[slot], c->stream));
-        HIP_TRY(c, hipStreamWaitEvent(c->sideStream, c->evRender[slot], 0));
-        const int rs = crt::launchSortUnits(c->dUnitCost[slot], c->dUnitOrder[slot], nUnits, c->sideStream);
+        hipStream_t ss = c->sortInline ? c->stream : c->sideStream;
+        if (!c->sortInline) HIP_TRY(c, hipStreamWaitEvent(ss, c->evRender[slot], 0));
+        const int rs = crt::launchSortUnits(c->dUnitCost[slot], c->dUnitOrder[slot], nUnits, ss);
         if (rs != 0) return fail(c, CRT_EHIP, "sort kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rs)));
-        HIP_TRY(c, hipEventRecord(c->evSort[slot], c->sideStream));
+        HIP_TRY(c, hipEventRecord(c->evSort[slot], ss));
         c->sortPending[slot] = true;
         c->orderKey[slot] = key;
-        c->frameSerial++;
     }
     if (stats) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -295,6 +304,18 @@ extern "C" {
 
 uint32_t crt_abi_version(void) { return CRT_ABI_VERSION; }
 
+namespace {
+hipError_t createRingEvents(crt_ctx* c)
+{
+    for (int i = 0; i < crt_ctx::kRing; i++) {
+        hipError_t e = hipEventCreateWithFlags(&c->evRender[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->evSort[i], hipEventDisableTiming);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+} // namespace
+
 int crt_create(crt_ctx** out, int device_id)
 {
     if (!out) return fail(nullptr, CRT_EINVAL, "crt_create: out is NULL");
@@ -311,8 +332,7 @@ int crt_create(crt_ctx** out, int device_id)
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->evRender[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evRender[1], hipEventDisableTiming)) != hipSuccess ||
-        (e = hipEventCreateWithFlags(&c->evSort[0], hipEventDisableTiming)) != hipSuccess || (e = hipEventCreateWithFlags(&c->evSort[1], hipEventDisableTiming)) != hipSuccess ||
+        (e = createRingEvents(c)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->dCounters), 16 * sizeof(unsigned long long))) != hipSuccess) {
         const int rc = fail(nullptr, CRT_ENODEVICE, "HIP initialisation failed on device %d: %s", device_id, hipGetErrorString(e));
         crt_destroy(c);
@@ -334,10 +354,10 @@ void crt_destroy(crt_ctx* c)
     if (c->dCounters) (void)hipFree(c->dCounters);
     if (c->dTextures) (void)hipFree(c->dTextures);
     if (c->dTexels) (void)hipFree(c->dTexels);
-    for (int i = 0; i < 2; i++)
+    for (int i = 0; i < crt_ctx::kRing; i++)
         if (c->dSpill[i]) (void)hipFree(c->dSpill[i]);
     if (c->sideStream) (void)hipStreamSynchronize(c->sideStream);
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < crt_ctx::kRing; i++) {
         if (c->dUnitCost[i]) (void)hipFree(c->dUnitCost[i]);
         if (c->dUnitOrder[i]) (void)hipFree(c->dUnitOrder[i]);
         if (c->evRender[i]) (void)hipEventDestroy(c->evRender[i]);
@@ -404,7 +424,13 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     const size_t tb = sizeof(crt_bvh_tri) * c->bvh.tris.size();
     const size_t sb = sizeof(crt_bvh_shade) * c->bvh.shade.size();
     // +64 bytes of slack so that a speculative wide load of the last record stays inside the allocation
+#if defined(CRT_EXP_DUP) && CRT_EXP_DUP == 2 // experiment build only: second copy of the tree 300000 nodes further on
+    if (c->bvh.nodes4.size() > 300000) return fail(c, CRT_EINVAL, "CRT_EXP_DUP build: scene too large");
+    HIP_TRY(c, hipMalloc(&c->dNodes, 300000 * 128 + nb + 256));
+    if (nb) HIP_TRY(c, hipMemcpy(static_cast<char*>(c->dNodes) + 300000 * 128, c->bvh.nodes4.data(), nb, hipMemcpyHostToDevice));
+#else
     HIP_TRY(c, hipMalloc(&c->dNodes, nb + 128));
+#endif
     HIP_TRY(c, hipMalloc(&c->dTris, tb + 64));
     HIP_TRY(c, hipMalloc(&c->dShade, sb + 64));
     HIP_TRY(c, hipMalloc(&c->dLights, sizeof(crt_light) * (n_lights + 1)));
@@ -424,7 +450,7 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     c->buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
     c->haveScene = true;
     c->sceneSerial++;
-    c->orderKey[0] = c->orderKey[1] = 0;
+    for (uint64_t& k : c->orderKey) k = 0;
     return CRT_OK;
 }
 
@@ -544,9 +570,13 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
         c->wantTimeline = value != 0;
         return CRT_OK;
     }
+    if (std::strcmp(name, "sort_inline") == 0) {
+        c->sortInline = value != 0;
+        return CRT_OK;
+    }
     if (std::strcmp(name, "adaptive_order") == 0) {
         c->adaptiveOrder = value != 0;
-        c->orderKey[0] = c->orderKey[1] = 0;
+        for (uint64_t& k : c->orderKey) k = 0;
         return CRT_OK;
     }
     if (std::strcmp(name, "stack_entries") == 0 && (value == 0 || (value >= 1 && value <= crt::kStackEntries))) {
