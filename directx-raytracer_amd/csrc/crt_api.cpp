@@ -61,8 +61,14 @@ struct crt_ctx {
     uint32_t tuneXcdGroup = 16;
     uint32_t tuneBoostUnits = 512;
     uint32_t debugSkipUnits = 0;
-    bool sortInline = false;
-    bool adaptiveOrder = true;     // launch the work units of frame N+1 in descending order of their cost in frame N
+    hipStream_t lastRenderStream = nullptr;
+    bool haveLastRenderStream = false;
+    // launch order from measured costs of an earlier frame: 0 never, 1 always, 2 (default) only for frames issued on the
+    // same stream as the frame before.  Such frames run one after another, and starting the packets on the longest
+    // critical paths first shortens each of them (0.52 -> 0.43 ms on the 1M-triangle frame); frames issued on
+    // alternating streams overlap, the tail of one fills with the head of the next, so the order has nothing left to
+    // gain and its bookkeeping only adds cross-stream dependencies (0.43 vs 0.40 ms per frame with 4 in flight).
+    int adaptiveOrder = 2;
     // Per-frame scratch lives in a ring of kRing slots: frame f uses slot f % kRing and first waits (on the GPU, never on
     // the host) for the frame that used the slot before it, so up to kRing frames issued on different streams run
     // concurrently without sharing a spill arena or a cost/order buffer.
@@ -219,7 +225,10 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
     const uint64_t key = (static_cast<uint64_t>(p.width) << 40) ^ (static_cast<uint64_t>(p.height) << 20) ^
                          (static_cast<uint64_t>(p.n_ranks) << 8) ^ p.rank ^ (static_cast<uint64_t>(c->sceneSerial) << 52) ^ 1ull;
     bool feedback = false;
-    if (c->adaptiveOrder && nUnits) {
+    const bool sameStream = c->haveLastRenderStream && c->lastRenderStream == c->stream;
+    c->lastRenderStream = c->stream;
+    c->haveLastRenderStream = true;
+    if ((c->adaptiveOrder == 1 || (c->adaptiveOrder == 2 && sameStream)) && nUnits) {
         if (c->unitCapacity < nUnits) {
             HIP_TRY(c, hipStreamSynchronize(c->sideStream));
             HIP_TRY(c, hipStreamSynchronize(c->stream));
@@ -253,8 +262,8 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
     HIP_TRY(c, hipEventRecord(c->evRender[slot], c->stream));
     c->renderPending[slot] = true;
     if (feedback) {
-        hipStream_t ss = c->sortInline ? c->stream : c->sideStream;
-        if (!c->sortInline) HIP_TRY(c, hipStreamWaitEvent(ss, c->evRender[slot], 0));
+        hipStream_t ss = c->sideStream;
+        HIP_TRY(c, hipStreamWaitEvent(ss, c->evRender[slot], 0));
         const int rs = crt::launchSortUnits(c->dUnitCost[slot], c->dUnitOrder[slot], nUnits, ss);
         if (rs != 0) return fail(c, CRT_EHIP, "sort kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rs)));
         HIP_TRY(c, hipEventRecord(c->evSort[slot], ss));
@@ -570,12 +579,9 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
         c->wantTimeline = value != 0;
         return CRT_OK;
     }
-    if (std::strcmp(name, "sort_inline") == 0) {
-        c->sortInline = value != 0;
-        return CRT_OK;
-    }
     if (std::strcmp(name, "adaptive_order") == 0) {
-        c->adaptiveOrder = value != 0;
+        if (value < 0 || value > 2) return fail(c, CRT_EINVAL, "adaptive_order takes 0 (off), 1 (on) or 2 (auto)");
+        c->adaptiveOrder = static_cast<int>(value);
         for (uint64_t& k : c->orderKey) k = 0;
         return CRT_OK;
     }

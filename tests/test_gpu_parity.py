@@ -209,14 +209,14 @@ def test_scheduling_knobs_never_change_results(pkg, oracle, scenes, dragon, rend
     renderer.change_shading_mode(100)
     w, h = 640, 360
     ref = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"]).render(cam["position"], cam["matrix"], 100, w, h)
-    defaults = {"inner_min": 32, "xcd_group": 16, "adaptive_order": 1, "boost_units": 512, "stack_entries": 0}
+    defaults = {"inner_min": 32, "xcd_group": 16, "adaptive_order": 2, "boost_units": 512, "stack_entries": 0}
     try:
-        for name, values in (("inner_min", (1, 7, 33, 65)), ("xcd_group", (1, 4)), ("adaptive_order", (0, 1)),
+        for name, values in (("inner_min", (1, 7, 33, 65)), ("xcd_group", (1, 4)), ("adaptive_order", (0, 1, 2)),
                              ("boost_units", (0, 100000)), ("stack_entries", (1, 2, 5, 16, 32))):  # 1..5: the spill arena carries most of the stack
             for v in values:
                 renderer.set_option(name, v)
                 renderer.set_counting(True)
-                for frame in range(3):  # frames 2 and 3 run in the cost-sorted order of the previous one
+                for frame in range(10):  # from frame 4 on (ring of 4 slots) the launch order comes from an earlier frame's costs
                     got = renderer.render_frame(w, h)
                     for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
                         np.testing.assert_array_equal(got[k], ref[k], err_msg="%s=%d frame %d %s" % (name, v, frame, k))
@@ -490,3 +490,43 @@ def test_textured_scene(pkg, oracle, scenes, renderer):
     got = renderer.render_frame(64, 64)
     ref = O2.render(cam["position"], cam["matrix"], 100, 64, 64)
     np.testing.assert_array_equal(got["rgba8"], ref["rgba8"])
+
+
+def test_frames_in_flight_and_launch_order_feedback(pkg, oracle, scenes, dragon, renderer):
+    """Many frames issued back to back on alternating streams (the ring of per-frame scratch slots, the cost-bucketed
+    launch queues taken from and refilled by every frame, the in-kernel recycling of a consumed queue): every frame,
+    rendered into its own sentinel-filled buffer, must be the oracle's frame -- a work unit rendered twice or never
+    would leave sentinel pixels.  Resolution changes in between invalidate the queues (stale, never-consumed ones are
+    cleared on the stream)."""
+    import torch
+    sc = _with_normals(scenes, dragon)
+    cam = sc["camera"]
+    renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+    renderer.set_camera(cam["position"], cam["matrix"])
+    renderer.change_shading_mode(100)
+    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    refs = {}
+    streams = [torch.cuda.Stream() for _ in range(5)]  # more streams than ring slots
+    try:
+      for policy, n_streams in ((1, 5), (2, 5), (2, 1), (1, 1), (0, 3)):  # feedback forced on / auto / off; 1 stream = auto turns it on
+        renderer.set_option("adaptive_order", policy)
+        n = 0
+        for (w, h), frames in (((640, 360), 13), ((333, 217), 9), ((640, 360), 11), ((64, 64), 10)):
+            if (w, h) not in refs:
+                refs[(w, h)] = O.render(cam["position"], cam["matrix"], 100, w, h)["rgba8"].reshape(-1, 4).copy().view(np.uint32).ravel()
+            bufs = [torch.full((w * h,), 0x7E57AB1E, dtype=torch.int32, device="cuda") for _ in range(frames)]
+            torch.cuda.synchronize()
+            for b in bufs:
+                st = streams[n % n_streams]
+                n += 1
+                renderer.set_stream(st.cuda_stream)
+                renderer.render_frame_device(w, h, b.data_ptr())
+            torch.cuda.synchronize()
+            for i, b in enumerate(bufs):
+                got = b.cpu().numpy().view(np.uint32)
+                assert np.array_equal(got, refs[(w, h)]), "policy %d, %d streams, %dx%d frame %d: %d pixels differ" % (
+                    policy, n_streams, w, h, i, int((got != refs[(w, h)]).sum()))
+    finally:
+        torch.cuda.synchronize()
+        renderer.set_option("adaptive_order", 2)
+        renderer.reset_stream()

@@ -17,8 +17,8 @@ W, H = 1920, 1080
 n_fly = 4
 streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_fly - 1)]
 import statistics
-for N, adaptive in ((1, 1), (1, 2), (1, 0), (4, 1), (4, 2), (4, 0), (8, 1), (8, 2), (8, 0)):
-    r.set_option("adaptive_order", 1 if adaptive else 0); r.set_option("sort_inline", 1 if adaptive == 2 else 0)
+for N, adaptive in ((1, 2), (1, 1), (1, 0), (2, 2), (4, 2), (8, 2), (8, 0)):
+    r.set_option("adaptive_order", adaptive)
     share = host.rank_share(W, H, 0, N)
     staging = [torch.zeros(share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
     gathered = [torch.zeros(N * share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
