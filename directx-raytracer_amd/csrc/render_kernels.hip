@@ -56,6 +56,9 @@ constexpr uint32_t kBoostAfter = 300;
 #else
 #define CRT_OCCUPANCY_ATTR
 #endif
+#ifndef UNIFORM_DESCENT
+#define UNIFORM_DESCENT 1
+#endif
 #ifndef PACKED_SLAB
 #define PACKED_SLAB 1
 #endif
@@ -262,6 +265,32 @@ __device__ __forceinline__ void slab4(const float4& mnx, const float4& mxx, cons
     }
 }
 
+// one wide node in registers; fetched per lane (seven dwordx4 vector loads) or, when the whole wavefront stands on the
+// same node, once through the scalar cache (constant address space + wave-uniform address = s_load)
+struct NodeRegs {
+    float4 q0, q1, q2, q3, q4, q5;
+    int4 refs;
+};
+__device__ __forceinline__ NodeRegs loadNode(const float4* __restrict__ N)
+{
+    NodeRegs nd;
+    nd.q0 = N[0]; nd.q1 = N[1]; nd.q2 = N[2]; nd.q3 = N[3]; nd.q4 = N[4]; nd.q5 = N[5];
+    nd.refs = *reinterpret_cast<const int4*>(N + 6);
+    return nd;
+}
+__device__ __forceinline__ NodeRegs loadNodeUniform(const float4* N)
+{
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) f4v* ConstPtr;
+    ConstPtr C = (ConstPtr)(reinterpret_cast<uintptr_t>(N));
+    const f4v a = C[0], b = C[1], c = C[2], d = C[3], e = C[4], f = C[5], g = C[6];
+    NodeRegs nd;
+    nd.q0 = make_float4(a.x, a.y, a.z, a.w); nd.q1 = make_float4(b.x, b.y, b.z, b.w); nd.q2 = make_float4(c.x, c.y, c.z, c.w);
+    nd.q3 = make_float4(d.x, d.y, d.z, d.w); nd.q4 = make_float4(e.x, e.y, e.z, e.w); nd.q5 = make_float4(f.x, f.y, f.z, f.w);
+    nd.refs = make_int4(__float_as_int(g.x), __float_as_int(g.y), __float_as_int(g.z), __float_as_int(g.w));
+    return nd;
+}
+
 __device__ __forceinline__ int pick4(const int4& v, uint32_t i) // v[i], i in 0..3, without dynamic register indexing
 {
     const int lo = (i & 1u) ? v.y : v.x, hi = (i & 1u) ? v.w : v.z;
@@ -272,12 +301,11 @@ __device__ __forceinline__ int pick4(const int4& v, uint32_t i) // v[i], i in 0.
 // bit pattern orders like the float, the two low bits hold the slot (keys are unique, order is total and identical in
 // the oracle); misses get 0xFFFFFFFF.  Five min/max pairs sort the four keys.
 template <bool COUNT, int BLOCK, int OCT>
-__device__ __forceinline__ void nodeStepClosest(const float4* __restrict__ nodes, const Ray& r, float tmin, float tcull, Stack& stack,
-                                                int& cur, uint32_t& cntNodes)
+__device__ __forceinline__ void nodeStepClosestAt(const NodeRegs& nd, const Ray& r, float tmin, float tcull, Stack& stack,
+                                                  int& cur, uint32_t& cntNodes)
 {
-    const float4* N = nodes + 8 * static_cast<size_t>(cur);
-    const float4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3], q4 = N[4], q5 = N[5];
-    const int4 refs = *reinterpret_cast<const int4*>(N + 6);
+    const float4 q0 = nd.q0, q1 = nd.q1, q2 = nd.q2, q3 = nd.q3, q4 = nd.q4, q5 = nd.q5;
+    const int4 refs = nd.refs;
     if (COUNT) cntNodes++;
     float tn[4];
     bool hit[4];
@@ -303,12 +331,11 @@ __device__ __forceinline__ void nodeStepClosest(const float4* __restrict__ nodes
 
 // any hit: order independent, children taken in slot order
 template <bool COUNT, int BLOCK, int OCT>
-__device__ __forceinline__ void nodeStepAny(const float4* __restrict__ nodes, const Ray& r, float tmin, float tcull, Stack& stack,
-                                            int& cur, uint32_t& cntNodes)
+__device__ __forceinline__ void nodeStepAnyAt(const NodeRegs& nd, const Ray& r, float tmin, float tcull, Stack& stack,
+                                              int& cur, uint32_t& cntNodes)
 {
-    const float4* N = nodes + 8 * static_cast<size_t>(cur);
-    const float4 q0 = N[0], q1 = N[1], q2 = N[2], q3 = N[3], q4 = N[4], q5 = N[5];
-    const int4 refs = *reinterpret_cast<const int4*>(N + 6);
+    const float4 q0 = nd.q0, q1 = nd.q1, q2 = nd.q2, q3 = nd.q3, q4 = nd.q4, q5 = nd.q5;
+    const int4 refs = nd.refs;
     if (COUNT) cntNodes++;
     float tn[4];
     bool hit[4];
@@ -327,6 +354,34 @@ __device__ __forceinline__ void nodeStepAny(const float4* __restrict__ nodes, co
     }
 }
 
+template <bool COUNT, int BLOCK, int OCT>
+__device__ __forceinline__ void nodeStepClosest(const float4* __restrict__ nodes, const Ray& r, float tmin, float tcull, Stack& stack,
+                                                int& cur, uint32_t& cntNodes)
+{
+    nodeStepClosestAt<COUNT, BLOCK, OCT>(loadNode(nodes + 8 * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);
+}
+template <bool COUNT, int BLOCK, int OCT>
+__device__ __forceinline__ void nodeStepAny(const float4* __restrict__ nodes, const Ray& r, float tmin, float tcull, Stack& stack,
+                                            int& cur, uint32_t& cntNodes)
+{
+    nodeStepAnyAt<COUNT, BLOCK, OCT>(loadNode(nodes + 8 * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);
+}
+
+// Uniform descent: the rays of an 8x8 packet start at the root and usually agree on the first few nodes.  While every
+// active lane stands on the SAME inner node its record is fetched once through the scalar cache (the node address is
+// wave-uniform, so the loads become s_load) instead of 64 identical per-lane vector fetches; each lane still runs its own
+// slab tests, ordering and pushes, so results and counters are exactly those of the per-lane loop that follows.
+#if UNIFORM_DESCENT
+#define CRT_UNIFORM_DESCENT(STEP)                                                                                              \
+    for (;;) {                                                                                                                 \
+        const int c0 = __builtin_amdgcn_readfirstlane(cur);                                                                    \
+        if (c0 < 0 || __ballot(cur != c0) != 0ull) break;                                                                      \
+        STEP<COUNT, BLOCK, OCT>(loadNodeUniform(nodes + 8 * static_cast<size_t>(c0)), r, tmin, tcull, stack, cur, cntNodes);   \
+    }
+#else
+#define CRT_UNIFORM_DESCENT(STEP)
+#endif
+
 // Wave-level scheduling shared by both traversals.  Every lane walks its own ray in its own fixed order (so results
 // and counters do not depend on what the other lanes do), but WHEN a lane's next step runs is decided per wavefront:
 // node steps are issued while at least `innerMin` lanes still stand on inner nodes (or nobody waits at a leaf); then the
@@ -341,6 +396,7 @@ __device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes
     int cur = n_nodes ? 0 : kDone;
     stack.sp = 0;
     float tcull = tmax * kCullPad; // boxes are culled against best_t * pad; changes only when a hit is accepted
+    CRT_UNIFORM_DESCENT(nodeStepClosestAt)
     for (;;) {
         const unsigned long long innerMask = __ballot(cur >= 0);
         const unsigned long long leafMask = __ballot((cur < 0) & (cur != kDone));
@@ -425,6 +481,7 @@ __device__ __forceinline__ bool traceAnyOct(const float4* __restrict__ nodes, co
     int cur = n_nodes ? 0 : kDone;
     stack.sp = 0;
     const float tcull = tmax * kCullPad;
+    CRT_UNIFORM_DESCENT(nodeStepAnyAt)
     for (;;) {
         const unsigned long long innerMask = __ballot(cur >= 0);
         const unsigned long long leafMask = __ballot((cur < 0) & (cur != kDone));
