@@ -56,6 +56,9 @@ constexpr uint32_t kBoostAfter = 300;
 #else
 #define CRT_OCCUPANCY_ATTR
 #endif
+#ifndef UNIFORM_LEAF
+#define UNIFORM_LEAF 1
+#endif
 #ifndef UNIFORM_DESCENT
 #define UNIFORM_DESCENT 1
 #endif
@@ -291,6 +294,15 @@ __device__ __forceinline__ NodeRegs loadNodeUniform(const float4* N)
     return nd;
 }
 
+__device__ __forceinline__ void loadTriUniform(const float4* T, float4& a, float4& b, float4& c)
+{
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) f4v* ConstPtr;
+    ConstPtr C = (ConstPtr)(reinterpret_cast<uintptr_t>(T));
+    const f4v x = C[0], y = C[1], z = C[2];
+    a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w); c = make_float4(z.x, z.y, z.z, z.w);
+}
+
 __device__ __forceinline__ int pick4(const int4& v, uint32_t i) // v[i], i in 0..3, without dynamic register indexing
 {
     const int lo = (i & 1u) ? v.y : v.x, hi = (i & 1u) ? v.w : v.z;
@@ -423,6 +435,27 @@ __device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes
         if ((cur < 0) & (cur != kDone)) {
             const uint32_t code = static_cast<uint32_t>(~cur);
             const uint32_t first = code >> 3, cnt = code & 7u;
+#if UNIFORM_LEAF
+            const int lc0 = __builtin_amdgcn_readfirstlane(cur);
+            if (__ballot(cur != lc0) == 0ull) {
+                // every waiting lane stands on the same leaf: its triangles come through the scalar cache, once per wavefront
+                const uint32_t ucode = static_cast<uint32_t>(~lc0);
+                const uint32_t ufirst = ucode >> 3, ucnt = ucode & 7u;
+                for (uint32_t i = ufirst; i < ufirst + ucnt; i++) {
+                    float4 a, b, c;
+                    loadTriUniform(tris + 3 * static_cast<size_t>(i), a, b, c);
+                    if (COUNT) cntTris++;
+                    float t, u, v;
+                    if (triTest(r, a, b, c, tmin, t, u, v)) {
+                        const uint32_t gid = __float_as_uint(c.w);
+                        if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
+                            h.t = t; h.u = u; h.v = v; h.tri = i; h.gid = gid;
+                            tcull = t * kCullPad;
+                        }
+                    }
+                }
+            } else
+#endif
 #if LEAF_PAIRS
             // two triangles per memory round trip (same test order): the second record's loads overlap the first's
             for (uint32_t i = first; i < first + cnt; i += 2) {
@@ -508,6 +541,23 @@ __device__ __forceinline__ bool traceAnyOct(const float4* __restrict__ nodes, co
         if ((cur < 0) & (cur != kDone)) {
             const uint32_t code = static_cast<uint32_t>(~cur);
             const uint32_t first = code >> 3, cnt = code & 7u;
+#if UNIFORM_LEAF
+            const int lc0 = __builtin_amdgcn_readfirstlane(cur);
+            if (__ballot(cur != lc0) == 0ull) {
+                const uint32_t ucode = static_cast<uint32_t>(~lc0);
+                const uint32_t ufirst = ucode >> 3, ucnt = ucode & 7u;
+                for (uint32_t i = ufirst; i < ufirst + ucnt; i++) {
+                    float4 a, b, c;
+                    loadTriUniform(tris + 3 * static_cast<size_t>(i), a, b, c);
+                    if (COUNT) cntTris++;
+                    float t, u, v;
+                    if (triTest(r, a, b, c, tmin, t, u, v) & (t < tmax)) {
+                        occluded = true;
+                        break;
+                    }
+                }
+            } else
+#endif
             for (uint32_t i = first; i < first + cnt; i++) {
                 const float4* T = tris + 3 * static_cast<size_t>(i);
                 const float4 a = T[0], b = T[1], c = T[2];
