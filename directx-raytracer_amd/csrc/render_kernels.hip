@@ -56,6 +56,9 @@ constexpr uint32_t kBoostAfter = 300;
 #else
 #define CRT_OCCUPANCY_ATTR
 #endif
+#ifndef UNIFORM_STEP
+#define UNIFORM_STEP 1
+#endif
 #ifndef UNIFORM_LEAF
 #define UNIFORM_LEAF 1
 #endif
@@ -393,6 +396,21 @@ __device__ __forceinline__ void nodeStepAny(const float4* __restrict__ nodes, co
 #else
 #define CRT_UNIFORM_DESCENT(STEP)
 #endif
+// One node step of the lanes standing on inner nodes (called with exactly those lanes active): through the scalar cache
+// when they all stand on the same node, per lane otherwise.
+#if UNIFORM_STEP
+#define CRT_NODE_STEP(STEP)                                                                                                    \
+    {                                                                                                                          \
+        const int c0 = __builtin_amdgcn_readfirstlane(cur);                                                                    \
+        if (__ballot(cur != c0) == 0ull) {                                                                                     \
+            STEP<COUNT, BLOCK, OCT>(loadNodeUniform(nodes + 8 * static_cast<size_t>(c0)), r, tmin, tcull, stack, cur, cntNodes); \
+        } else {                                                                                                               \
+            STEP<COUNT, BLOCK, OCT>(loadNode(nodes + 8 * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);     \
+        }                                                                                                                      \
+    }
+#else
+#define CRT_NODE_STEP(STEP) STEP<COUNT, BLOCK, OCT>(loadNode(nodes + 8 * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);
+#endif
 
 // Wave-level scheduling shared by both traversals.  Every lane walks its own ray in its own fixed order (so results
 // and counters do not depend on what the other lanes do), but WHEN a lane's next step runs is decided per wavefront:
@@ -418,10 +436,10 @@ __device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes
 #if CRT_PROF
             const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-            if (cur >= 0) nodeStepClosest<COUNT, BLOCK, OCT>(nodes, r, tmin, tcull, stack, cur, cntNodes);
 #pragma unroll
-            for (int extra = 1; extra < NODE_STEPS; extra++) // more node steps per scheduling decision: fewer ballots/branches
-                if (cur >= 0) nodeStepClosest<COUNT, BLOCK, OCT>(nodes, r, tmin, tcull, stack, cur, cntNodes);
+            for (int rep = 0; rep < NODE_STEPS; rep++) { // several node steps per scheduling decision: fewer ballots/branches
+                if (cur >= 0) CRT_NODE_STEP(nodeStepClosestAt)
+            }
 #if CRT_PROF
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             stack.tNode += __builtin_amdgcn_s_memtime() - ts0; stack.itNode++; stack.lanesNode += __popcll(innerMask);
@@ -524,10 +542,10 @@ __device__ __forceinline__ bool traceAnyOct(const float4* __restrict__ nodes, co
 #if CRT_PROF
             const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-            if (cur >= 0) nodeStepAny<COUNT, BLOCK, OCT>(nodes, r, tmin, tcull, stack, cur, cntNodes);
 #pragma unroll
-            for (int extra = 1; extra < NODE_STEPS; extra++)
-                if (cur >= 0) nodeStepAny<COUNT, BLOCK, OCT>(nodes, r, tmin, tcull, stack, cur, cntNodes);
+            for (int rep = 0; rep < NODE_STEPS; rep++) {
+                if (cur >= 0) CRT_NODE_STEP(nodeStepAnyAt)
+            }
 #if CRT_PROF
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             stack.tNode += __builtin_amdgcn_s_memtime() - ts0; stack.itNode++; stack.lanesNode += __popcll(innerMask);
