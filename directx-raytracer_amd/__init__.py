@@ -14,7 +14,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcrt_hip.so")
+LIB_PATH = os.environ.get("CRT_HIP_LIBRARY") or os.path.join(_HERE, "libcrt_hip.so")  # the override is for A/B builds (tools/variant_build.sh)
 MISS = 0xFFFFFFFF
 MODE_LAMBERT = 100
 MODE_PATH = 200

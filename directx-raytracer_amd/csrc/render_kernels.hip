@@ -51,22 +51,15 @@ constexpr uint32_t kBoostAfter = 300;
 #else
 #define CRT_EXP_DUP_LOADS
 #endif
-#ifdef CRT_WAVES_PER_EU // experiment: ask the register allocator for this many wavefronts per SIMD
-#define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(CRT_WAVES_PER_EU, 8)))
-#else
-#define CRT_OCCUPANCY_ATTR
+// Register budget: the primary/shadow-ray variant is asked to fit 7 wavefronts per SIMD (<= 72 VGPRs; the LDS stacks then
+// allow 26 per CU), which measured 0.329 ms against 0.338 at the compiler's own choice of 78 VGPRs / 6 wavefronts and
+// 0.43 at 8 (spills).  The path-tracing variant keeps the compiler's choice: its live state does not fit.
+#ifndef CRT_WAVES_PER_EU
+#define CRT_WAVES_PER_EU 7
 #endif
-#ifndef UNIFORM_STEP
-#define UNIFORM_STEP 1
-#endif
-#ifndef UNIFORM_LEAF
-#define UNIFORM_LEAF 1
-#endif
-#ifndef UNIFORM_DESCENT
-#define UNIFORM_DESCENT 1
-#endif
+#define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(PATH ? 1 : CRT_WAVES_PER_EU, 8)))
 #ifndef PACKED_SLAB
-#define PACKED_SLAB 1
+#define PACKED_SLAB 0 // v_pk_fma_f32 for the slab planes: 12 fewer issue slots per node step but 10 more VGPRs; measured slower
 #endif
 #ifndef LEAF_PAIRS
 #define LEAF_PAIRS 1
@@ -284,7 +277,7 @@ __device__ __forceinline__ NodeRegs loadNode(const float4* __restrict__ N)
     nd.refs = *reinterpret_cast<const int4*>(N + 6);
     return nd;
 }
-__device__ __forceinline__ NodeRegs loadNodeUniform(const float4* N)
+__device__ __forceinline__ __attribute__((unused)) NodeRegs loadNodeUniform(const float4* N)
 {
     typedef float f4v __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) f4v* ConstPtr;
@@ -297,7 +290,7 @@ __device__ __forceinline__ NodeRegs loadNodeUniform(const float4* N)
     return nd;
 }
 
-__device__ __forceinline__ void loadTriUniform(const float4* T, float4& a, float4& b, float4& c)
+__device__ __forceinline__ __attribute__((unused)) void loadTriUniform(const float4* T, float4& a, float4& b, float4& c)
 {
     typedef float f4v __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) f4v* ConstPtr;

@@ -156,15 +156,17 @@ def test_tile_partition_reassembles_full_frame(pkg, scenes, dragon, renderer):
     renderer.change_shading_mode(100)
     for (w, h) in ((1920, 1080), (333, 77)):
         full = torch.zeros(h * w, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()  # the renderer's own stream does not order with torch's: the fill must have landed
         renderer.render_frame_device(w, h, full.data_ptr())
         renderer.synchronize()
         for n in (1, 2, 3, 8):
             slots = pkg.tile_slots(w, h, n)
             gathered = torch.zeros(n * slots * 256, dtype=torch.int32, device="cuda")
+            frame = torch.zeros(h * w, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
             for rank in range(n):
                 st = renderer.render_tiles_device(w, h, rank, n, gathered.data_ptr() + rank * slots * 1024, stats=True)
                 assert st["rays_primary"] > 0
-            frame = torch.zeros(h * w, dtype=torch.int32, device="cuda")
             renderer.untile_device(w, h, n, gathered.data_ptr(), frame.data_ptr())
             renderer.synchronize()
             assert torch.equal(frame, full), (w, h, n)
@@ -305,6 +307,7 @@ def test_c5_full_size_properties(pkg, scenes, renderer):
         a = torch.zeros(h * w, dtype=torch.int32, device="cuda")
         b = torch.zeros(h * w, dtype=torch.int32, device="cuda")
         rgb = torch.zeros(h * w * 3, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()  # own stream vs torch's fill kernels
         renderer.set_counting(True)
         st = renderer.render_frame_device(w, h, a.data_ptr(), d_rgb=rgb.data_ptr(), stats=True)
         renderer.set_counting(False)
@@ -316,6 +319,7 @@ def test_c5_full_size_properties(pkg, scenes, renderer):
         n = 8
         slots = pkg.tile_slots(w, h, n)
         gathered = torch.zeros(n * slots * 256, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
         for rank in range(n):
             renderer.render_tiles_device(w, h, rank, n, gathered.data_ptr() + rank * slots * 1024)
         renderer.untile_device(w, h, n, gathered.data_ptr(), b.data_ptr())

@@ -5,6 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import __graft_entry__ as entry
 ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--mode", type=int, default=100)
+ap.add_argument("--opt", default=None, help="name=v1,v2,...: also sweep a crt_set_option knob for every library")
 ap.add_argument("--rounds", type=int, default=6); ap.add_argument("--frames", type=int, default=20)
 a = ap.parse_args()
 import torch
@@ -18,11 +19,14 @@ for path in a.libs:
     L = pkg.lib()
     r = pkg.Renderer(0); r.upload(sc["meshes"], sc["lights"], sc["materials"]); r.set_camera(sc["camera"]["position"], sc["camera"]["matrix"]); r.change_shading_mode(a.mode)
     rs.append((path, L, r))
-res = {p: [] for p, _, _ in rs}
+oname, ovals = (a.opt.split("=")[0], [int(v) for v in a.opt.split("=")[1].split(",")]) if a.opt else (None, [None])
+res = {(p, v): [] for p, _, _ in rs for v in ovals}
 for rnd in range(a.rounds + 1):
     for path, L, r in rs:
         pkg._lib = L
-        ms = [r.render_frame_device(W, H, frame.data_ptr(), stats=True)["kernel_ms"] for _ in range(a.frames)]
-        if rnd: res[path].append(statistics.median(ms))
-for path in res:
-    print("%-40s median %.4f ms  min %.4f ms" % (os.path.basename(path), statistics.median(res[path]), min(res[path])), flush=True)
+        for v in ovals:
+            if oname: r.set_option(oname, v); r.render_frame_device(W, H, frame.data_ptr(), stats=True)
+            ms = [r.render_frame_device(W, H, frame.data_ptr(), stats=True)["kernel_ms"] for _ in range(a.frames)]
+            if rnd: res[(path, v)].append(statistics.median(ms))
+for (path, v) in res:
+    print("%-32s %-18s median %.4f ms  min %.4f ms" % (os.path.basename(path), "" if v is None else "%s=%d" % (oname, v), statistics.median(res[(path, v)]), min(res[(path, v)])), flush=True)
