@@ -58,6 +58,17 @@ constexpr uint32_t kBoostAfter = 300;
 #define CRT_WAVES_PER_EU 7
 #endif
 #define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(PATH ? 1 : CRT_WAVES_PER_EU, 8)))
+// scalar-cache fetches of records a whole wavefront shares (see loadNodeUniform): in the descent from the root, in any
+// node step whose lanes agree, and in leaves
+#ifndef UNIFORM_DESCENT
+#define UNIFORM_DESCENT 1
+#endif
+#ifndef UNIFORM_STEP
+#define UNIFORM_STEP 1
+#endif
+#ifndef UNIFORM_LEAF
+#define UNIFORM_LEAF 1
+#endif
 #ifndef PACKED_SLAB
 #define PACKED_SLAB 0 // v_pk_fma_f32 for the slab planes: 12 fewer issue slots per node step but 10 more VGPRs; measured slower
 #endif

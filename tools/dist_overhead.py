@@ -17,7 +17,7 @@ W, H = 1920, 1080
 n_fly = 4
 streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_fly - 1)]
 import statistics
-for N, adaptive in ((1, 2), (1, 1), (1, 0), (2, 2), (4, 2), (8, 2), (8, 0)):
+for N, adaptive in ((1, 2), (1, 1), (1, 0), (2, 1), (2, 0), (4, 1), (4, 0), (8, 1), (8, 0)):
     r.set_option("adaptive_order", adaptive)
     share = host.rank_share(W, H, 0, N)
     staging = [torch.zeros(share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
