@@ -78,6 +78,9 @@ struct crt_ctx {
     uint32_t unitCapacity = 0;
     uint64_t orderKey[kRing] = {};   // frame geometry each stored order belongs to; 0 = none
     bool sortPending[kRing] = {};    // evSort[slot] recorded (a sort of this slot's costs was issued)
+    uint32_t orderView[kRing] = {};  // viewSerial the stored order was measured under
+    uint32_t orderGen[kRing] = {};   // consecutive sorts under that view
+    uint32_t viewSerial = 1;         // bumped when camera, mode or path settings change: costs must be measured again
     bool renderPending[kRing] = {};  // evRender[slot] recorded
     uint32_t frameSerial = 0;
     hipStream_t sideStream = nullptr; // sorts the costs of frame f while later frames render
@@ -246,9 +249,17 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
             }
             c->unitCapacity = nUnits;
         }
-        p.unit_cost = c->dUnitCost[slot];
-        p.unit_order = c->orderKey[slot] == key ? c->dUnitOrder[slot] : nullptr;
-        feedback = true;
+        const bool usable = c->orderKey[slot] == key;
+        p.unit_order = usable ? c->dUnitOrder[slot] : nullptr;
+        // an unchanged view keeps its order: costs are measured (and sorted) again only after camera / mode / scene changed,
+        // twice, because the first measurement was taken under an unordered launch
+        const bool settled = usable && c->orderView[slot] == c->viewSerial && c->orderGen[slot] >= 2;
+        if (!settled) {
+            p.unit_cost = c->dUnitCost[slot];
+            feedback = true;
+            c->orderGen[slot] = (usable && c->orderView[slot] == c->viewSerial) ? c->orderGen[slot] + 1 : 1;
+            c->orderView[slot] = c->viewSerial;
+        }
     }
     // the previous user of this slot (frame f - kRing, possibly on another stream) and the sort of its costs must be done
     // before this frame touches the slot's spill arena, cost or order buffer
@@ -314,6 +325,15 @@ extern "C" {
 uint32_t crt_abi_version(void) { return CRT_ABI_VERSION; }
 
 namespace {
+// the 1-workgroup sort that orders a later frame runs beside the next frame's render kernel: highest priority, so it is
+// dispatched at once instead of queueing behind 32 640 render workgroups
+hipError_t createSideStream(crt_ctx* c)
+{
+    int least = 0, greatest = 0;
+    hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(&c->sideStream, hipStreamNonBlocking, greatest);
+}
 hipError_t createRingEvents(crt_ctx* c)
 {
     for (int i = 0; i < crt_ctx::kRing; i++) {
@@ -340,7 +360,7 @@ int crt_create(crt_ctx** out, int device_id)
     c->device = device_id;
     if ((e = hipSetDevice(device_id)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
-        (e = hipStreamCreateWithFlags(&c->sideStream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = createSideStream(c)) != hipSuccess ||
         (e = createRingEvents(c)) != hipSuccess ||
         (e = hipMalloc(reinterpret_cast<void**>(&c->dCounters), 16 * sizeof(unsigned long long))) != hipSuccess) {
         const int rc = fail(nullptr, CRT_ENODEVICE, "HIP initialisation failed on device %d: %s", device_id, hipGetErrorString(e));
@@ -513,6 +533,7 @@ int crt_set_camera(crt_ctx* c, const float pos[3], const float rot[9])
 {
     if (!c) return CRT_EINVAL;
     if (!pos || !rot) return fail(c, CRT_EINVAL, "crt_set_camera: NULL argument");
+    if (std::memcmp(c->pos, pos, sizeof(c->pos)) != 0 || std::memcmp(c->rot, rot, sizeof(c->rot)) != 0) c->viewSerial++;
     std::memcpy(c->pos, pos, sizeof(c->pos));
     std::memcpy(c->rot, rot, sizeof(c->rot));
     return CRT_OK;
@@ -521,6 +542,7 @@ int crt_set_camera(crt_ctx* c, const float pos[3], const float rot[9])
 int crt_set_shading_mode(crt_ctx* c, uint32_t mode)
 {
     if (!c) return CRT_EINVAL;
+    if (c->mode != mode) c->viewSerial++;
     c->mode = mode;
     return CRT_OK;
 }
@@ -549,10 +571,12 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
     }
     if (std::strcmp(name, "spp") == 0 && value >= 1 && value <= 65536) {
         c->pathSpp = static_cast<uint32_t>(value);
+        c->viewSerial++;
         return CRT_OK;
     }
     if (std::strcmp(name, "max_bounces") == 0 && value >= 0 && value <= 64) {
         c->pathBounces = static_cast<uint32_t>(value);
+        c->viewSerial++;
         return CRT_OK;
     }
     if (std::strcmp(name, "seed") == 0) {

@@ -1128,35 +1128,46 @@ int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream)
 }
 
 // Order the work units by descending cost (counting sort on min(cost, 1023); order inside a bucket is arbitrary).
-__global__ __launch_bounds__(1024) void sortUnitsKernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n)
+// One 256-thread workgroup: small enough to be placed on a CU beside resident render wavefronts (a 1024-thread group
+// waited for 16 free wave slots on one CU, i.e. for the next frame's render kernel to drain).
+constexpr uint32_t kSortThreads = 256, kSortBuckets = 1024, kSortPerThread = kSortBuckets / kSortThreads;
+__global__ __launch_bounds__(kSortThreads) void sortUnitsKernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n)
 {
-    __shared__ uint32_t hist[1024];
-    __shared__ uint32_t offs[1024];
+    __shared__ uint32_t hist[kSortBuckets];
+    __shared__ uint32_t sums[kSortThreads];
     const uint32_t t = threadIdx.x;
-    hist[t] = 0;
+    for (uint32_t b = t; b < kSortBuckets; b += kSortThreads) hist[b] = 0;
     __syncthreads();
-    for (uint32_t i = t; i < n; i += 1024u) atomicAdd(&hist[min(cost[i], 1023u)], 1u);
+    for (uint32_t i = t; i < n; i += kSortThreads) atomicAdd(&hist[min(cost[i], kSortBuckets - 1u)], 1u);
     __syncthreads();
-    // bucket 1023 first: offs[b] = number of units in buckets above b (inclusive scan over the reversed histogram)
-    uint32_t v = hist[1023u - t];
-    offs[t] = v;
+    // most expensive bucket first: thread t owns the reversed buckets 4t..4t+3
+    uint32_t local[kSortPerThread], total = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < kSortPerThread; k++) {
+        local[k] = hist[kSortBuckets - 1u - (t * kSortPerThread + k)];
+        total += local[k];
+    }
+    sums[t] = total;
     __syncthreads();
-    for (uint32_t d = 1; d < 1024u; d <<= 1) {
-        const uint32_t add = t >= d ? offs[t - d] : 0u;
+    for (uint32_t d = 1; d < kSortThreads; d <<= 1) { // inclusive scan of the per-thread totals
+        const uint32_t add = t >= d ? sums[t - d] : 0u;
         __syncthreads();
-        offs[t] += add;
+        sums[t] += add;
         __syncthreads();
     }
-    const uint32_t excl = offs[t] - v; // exclusive prefix of reversed bucket t
+    uint32_t base = sums[t] - total;
+#pragma unroll
+    for (uint32_t k = 0; k < kSortPerThread; k++) { // hist[b] = first output slot of bucket b
+        hist[kSortBuckets - 1u - (t * kSortPerThread + k)] = base;
+        base += local[k];
+    }
     __syncthreads();
-    hist[1023u - t] = excl;            // hist[b] now = first output slot of bucket b
-    __syncthreads();
-    for (uint32_t i = t; i < n; i += 1024u) order[atomicAdd(&hist[min(cost[i], 1023u)], 1u)] = i;
+    for (uint32_t i = t; i < n; i += kSortThreads) order[atomicAdd(&hist[min(cost[i], kSortBuckets - 1u)], 1u)] = i;
 }
 
 int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, ihipStream_t* stream)
 {
-    hipLaunchKernelGGL(sortUnitsKernel, dim3(1), dim3(1024), 0, stream, cost, order, n);
+    hipLaunchKernelGGL(sortUnitsKernel, dim3(1), dim3(kSortThreads), 0, stream, cost, order, n);
     return static_cast<int>(hipGetLastError());
 }
 
