@@ -51,11 +51,11 @@ constexpr uint32_t kBoostAfter = 300;
 #else
 #define CRT_EXP_DUP_LOADS
 #endif
-// Register budget: the primary/shadow-ray variant is asked to fit 7 wavefronts per SIMD (<= 72 VGPRs; the LDS stacks then
-// allow 26 per CU), which measured 0.329 ms against 0.338 at the compiler's own choice of 78 VGPRs / 6 wavefronts and
-// 0.43 at 8 (spills).  The path-tracing variant keeps the compiler's choice: its live state does not fit.
+// Register budget: the primary/shadow-ray variant is asked for at least 6 wavefronts per SIMD (<= 80 VGPRs; it needs 78,
+// and the LDS stacks allow 26 wavefronts per CU).  7 (72 VGPRs, 36 B/lane spilled) measured 0.330 ms against 0.325,
+// 8 spills inside the loop (0.43).  The path-tracing variant keeps the compiler's choice: its live state does not fit.
 #ifndef CRT_WAVES_PER_EU
-#define CRT_WAVES_PER_EU 7
+#define CRT_WAVES_PER_EU 6
 #endif
 #define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(PATH ? 1 : CRT_WAVES_PER_EU, 8)))
 // scalar-cache fetches of records a whole wavefront shares (see loadNodeUniform): in the descent from the root, in any

@@ -38,9 +38,15 @@ def _compare(pkg, oracle, renderer, sc, w, h, modes, exact_float=True, count=Tru
     assert nodes4.tobytes() == O.nodes4().tobytes() and depth4 == O.depth4
     for mode in modes:
         renderer.change_shading_mode(mode)
+        ref = O.render(cam["position"], cam["matrix"], mode, w, h)
+        if count:  # the plain (non-instrumented) kernel variant is the product: it must give the same frame
+            renderer.set_counting(False)
+            plain = renderer.render_frame(w, h)
+            for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
+                np.testing.assert_array_equal(plain[k], ref[k], err_msg="mode %d %s (plain kernel)" % (mode, k))
+            assert np.array_equal(plain["rgb"], ref["rgb"], equal_nan=True), "mode %d rgb (plain kernel)" % mode
         renderer.set_counting(count)
         got = renderer.render_frame(w, h)
-        ref = O.render(cam["position"], cam["matrix"], mode, w, h)
         np.testing.assert_array_equal(got["hit_inst"], ref["hit_inst"], err_msg="mode %d hit_inst" % mode)
         np.testing.assert_array_equal(got["hit_prim"], ref["hit_prim"], err_msg="mode %d hit_prim" % mode)
         np.testing.assert_array_equal(got["hit_t"], ref["hit_t"], err_msg="mode %d hit_t" % mode)
@@ -249,6 +255,11 @@ def _compare_path(pkg, oracle, renderer, sc, w, h, spp, bounces, seed, miss=(0.0
     try:
         got = renderer.render_frame(w, h)
         ref = O.render(cam["position"], cam["matrix"], oracle.MODE_PATH, w, h, miss_rgb=miss)
+        renderer.set_counting(False)  # the plain kernel variant is the product
+        plain = renderer.render_frame(w, h)
+        for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
+            np.testing.assert_array_equal(plain[k], ref[k], err_msg=k + " (plain kernel)")
+        assert np.array_equal(plain["rgb"], ref["rgb"], equal_nan=True), "path-traced rgb (plain kernel)"
     finally:
         oracle.set_path_params(4, 3, 1234)
         renderer.set_path_params(4, 3, 1234)
