@@ -453,13 +453,7 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     const size_t tb = sizeof(crt_bvh_tri) * c->bvh.tris.size();
     const size_t sb = sizeof(crt_bvh_shade) * c->bvh.shade.size();
     // +64 bytes of slack so that a speculative wide load of the last record stays inside the allocation
-#if defined(CRT_EXP_DUP) && CRT_EXP_DUP == 2 // experiment build only: second copy of the tree 300000 nodes further on
-    if (c->bvh.nodes4.size() > 300000) return fail(c, CRT_EINVAL, "CRT_EXP_DUP build: scene too large");
-    HIP_TRY(c, hipMalloc(&c->dNodes, 300000 * 128 + nb + 256));
-    if (nb) HIP_TRY(c, hipMemcpy(static_cast<char*>(c->dNodes) + 300000 * 128, c->bvh.nodes4.data(), nb, hipMemcpyHostToDevice));
-#else
     HIP_TRY(c, hipMalloc(&c->dNodes, nb + 128));
-#endif
     HIP_TRY(c, hipMalloc(&c->dTris, tb + 64));
     HIP_TRY(c, hipMalloc(&c->dShade, sb + 64));
     HIP_TRY(c, hipMalloc(&c->dLights, sizeof(crt_light) * (n_lights + 1)));

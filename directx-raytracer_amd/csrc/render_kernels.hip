@@ -36,21 +36,6 @@ constexpr uint32_t kBoostAfter = 300;
 #ifndef CRT_PROF
 #define CRT_PROF 0
 #endif
-#ifndef CRT_EXP_DUP
-#define CRT_EXP_DUP 0
-#endif
-// experiment (tools/variant_build.sh): a second node's worth of loads per node step -- 1 = the neighbouring node (twice the
-// L1 requests, same footprint), 2 = a second copy of the tree kExpDupNodes nodes further on (twice the footprint too)
-#if CRT_EXP_DUP
-#define CRT_EXP_DUP_LOADS                                                                                                      \
-    {                                                                                                                          \
-        const float4* M = CRT_EXP_DUP == 1 ? nodes + 8 * static_cast<size_t>(cur ^ 1) : N + 8 * static_cast<size_t>(300000);   \
-        const float4 d0 = M[0], d1 = M[1], d2 = M[2], d3 = M[3], d4 = M[4], d5 = M[5], d6 = M[6];                              \
-        if (d0.x + d1.y + d2.z + d3.w + d4.x + d5.y + d6.z == 1.2345e37f) tn[0] = 0.0f;                                        \
-    }
-#else
-#define CRT_EXP_DUP_LOADS
-#endif
 // Register budget: the primary/shadow-ray variant is asked for at least 6 wavefronts per SIMD (<= 80 VGPRs; it needs 78,
 // and the LDS stacks allow 26 wavefronts per CU).  7 (72 VGPRs, 36 B/lane spilled) measured 0.330 ms against 0.325,
 // 8 spills inside the loop (0.43).  The path-tracing variant keeps the compiler's choice: its live state does not fit.
@@ -68,9 +53,6 @@ constexpr uint32_t kBoostAfter = 300;
 #endif
 #ifndef UNIFORM_LEAF
 #define UNIFORM_LEAF 1
-#endif
-#ifndef PACKED_SLAB
-#define PACKED_SLAB 0 // v_pk_fma_f32 for the slab planes: 12 fewer issue slots per node step but 10 more VGPRs; measured slower
 #endif
 #ifndef LEAF_PAIRS
 #define LEAF_PAIRS 1
@@ -235,33 +217,6 @@ template <int OCT>
 __device__ __forceinline__ void slab4(const float4& mnx, const float4& mxx, const float4& mny, const float4& mxy, const float4& mnz,
                                       const float4& mxz, const Ray& r, float tmin, float tcull, float tn[4], bool hit[4])
 {
-#if PACKED_SLAB
-    if (OCT < 8) {
-        // the 24 plane distances as 12 packed FMAs (v_pk_fma_f32: two IEEE fmas per issue slot, same results as scalar fmaf)
-        typedef float v2f __attribute__((ext_vector_type(2)));
-        const float4& nx4 = (OCT & 1) ? mxx : mnx; const float4& fx4 = (OCT & 1) ? mnx : mxx;
-        const float4& ny4 = (OCT & 2) ? mxy : mny; const float4& fy4 = (OCT & 2) ? mny : mxy;
-        const float4& nz4 = (OCT & 4) ? mxz : mnz; const float4& fz4 = (OCT & 4) ? mnz : mxz;
-        const v2f ix = { r.idir.x, r.idir.x }, iy = { r.idir.y, r.idir.y }, iz = { r.idir.z, r.idir.z };
-        const v2f ox = { r.noid.x, r.noid.x }, oy = { r.noid.y, r.noid.y }, oz = { r.noid.z, r.noid.z };
-#define CRT_PK(q, lo, hi, i, o) __builtin_elementwise_fma(v2f{ q.lo, q.hi }, i, o)
-        const v2f nxa = CRT_PK(nx4, x, y, ix, ox), nxb = CRT_PK(nx4, z, w, ix, ox), fxa = CRT_PK(fx4, x, y, ix, ox), fxb = CRT_PK(fx4, z, w, ix, ox);
-        const v2f nya = CRT_PK(ny4, x, y, iy, oy), nyb = CRT_PK(ny4, z, w, iy, oy), fya = CRT_PK(fy4, x, y, iy, oy), fyb = CRT_PK(fy4, z, w, iy, oy);
-        const v2f nza = CRT_PK(nz4, x, y, iz, oz), nzb = CRT_PK(nz4, z, w, iz, oz), fza = CRT_PK(fz4, x, y, iz, oz), fzb = CRT_PK(fz4, z, w, iz, oz);
-#undef CRT_PK
-        const float nX[4] = { nxa.x, nxa.y, nxb.x, nxb.y }, fX[4] = { fxa.x, fxa.y, fxb.x, fxb.y };
-        const float nY[4] = { nya.x, nya.y, nyb.x, nyb.y }, fY[4] = { fya.x, fya.y, fyb.x, fyb.y };
-        const float nZ[4] = { nza.x, nza.y, nzb.x, nzb.y }, fZ[4] = { fza.x, fza.y, fzb.x, fzb.y };
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const float tnk = fmaxf(fmaxf(nX[k], nY[k]), fmaxf(nZ[k], tmin));
-            const float tfk = fminf(fminf(fX[k], fY[k]), fminf(fZ[k], tcull));
-            tn[k] = tnk;
-            hit[k] = tnk <= tfk;
-        }
-        return;
-    }
-#endif
     const float ax[4] = { mnx.x, mnx.y, mnx.z, mnx.w }, bx[4] = { mxx.x, mxx.y, mxx.z, mxx.w };
     const float ay[4] = { mny.x, mny.y, mny.z, mny.w }, by[4] = { mxy.x, mxy.y, mxy.z, mxy.w };
     const float az[4] = { mnz.x, mnz.y, mnz.z, mnz.w }, bz[4] = { mxz.x, mxz.y, mxz.z, mxz.w };
@@ -329,7 +284,6 @@ __device__ __forceinline__ void nodeStepClosestAt(const NodeRegs& nd, const Ray&
     float tn[4];
     bool hit[4];
     slab4<OCT>(q0, q1, q2, q3, q4, q5, r, tmin, tcull, tn, hit);
-    CRT_EXP_DUP_LOADS
     const int rf[4] = { refs.x, refs.y, refs.z, refs.w };
     uint32_t key[4];
 #pragma unroll
@@ -359,7 +313,6 @@ __device__ __forceinline__ void nodeStepAnyAt(const NodeRegs& nd, const Ray& r, 
     float tn[4];
     bool hit[4];
     slab4<OCT>(q0, q1, q2, q3, q4, q5, r, tmin, tcull, tn, hit);
-    CRT_EXP_DUP_LOADS
     const bool h0 = hit[0] & (refs.x != kEmptyRef), h1 = hit[1] & (refs.y != kEmptyRef), h2 = hit[2] & (refs.z != kEmptyRef),
                h3 = hit[3] & (refs.w != kEmptyRef);
     if (!(h0 | h1 | h2 | h3)) {
