@@ -79,6 +79,7 @@ def main():
                     "N=1 (launches back to back on ONE stream, so the HIP events over the timed region measure the kernel's average "
                     "launch duration and the rocprofv3 summary of the same command agrees with it), 4 at N>1 (the tail of one "
                     "rank's tile launch and the all-gather overlap the next frame)")
+    ap.add_argument("--batch", type=int, default=2, help="N>1 only: frames per launch (1..4) of each rank's tile share")
     ap.add_argument("--force-dist", action="store_true", help="rehearse the N>1 code path (RCCL init, tile staging, all-gather, "
                     "de-interleave) with whatever world size the launcher gives, even 1")
     args = ap.parse_args()
@@ -120,6 +121,7 @@ def main():
     r.set_camera(cam["position"], cam["matrix"])
     r.change_shading_mode(MODE)
     n_fly = args.inflight if args.inflight > 0 else (4 if multi else 1)
+    batch = max(1, min(4, args.batch)) if multi else 1
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_fly - 1)]
     stream = streams[0]
     r.set_stream(stream.cuda_stream)  # the kernels run on torch streams: torch events and RCCL order with them
@@ -139,26 +141,42 @@ def main():
             r.set_stream(streams[k].cuda_stream)
             r.render_frame_device(W, H, frames[k].data_ptr())
     else:
+        # N > 1: each launch carries `batch` consecutive frames of this rank's tile share (crt_render_tiles_batch_device): a
+        # launch lasts as long as its slowest packet, and a 1/N share has the same slowest packet as the whole frame
         share = host.rank_share(W, H, rank, world)
-        staging = [torch.zeros(share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
-        gathered = [torch.zeros(world * share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
+        staging = [[torch.zeros(share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(batch)] for _ in range(n_fly)]
+        gathered = [[torch.zeros(world * share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(batch)] for _ in range(n_fly)]
+        out = [[torch.zeros(W * H, dtype=torch.int32, device="cuda") for _ in range(batch)] for _ in range(n_fly)]
+        launches = [0]
 
         def step(i):
-            k = i % n_fly
+            # frames i, i+1, ... of one batch are issued when its first frame is due; the others are already covered
+            if i % batch:
+                return
+            nb = min(batch, step.total - i)
+            k = launches[0] % n_fly
+            launches[0] += 1
             r.set_stream(streams[k].cuda_stream)
             with torch.cuda.stream(streams[k]):
-                r.render_tiles_device(W, H, rank, world, staging[k].data_ptr())
-                host.gather_frame(staging[k], W, H, lambda g, k=k: (r.untile_device(W, H, world, g.data_ptr(), frames[k].data_ptr()), frames[k])[1],
-                                  gathered[k])
+                r.render_tiles_batch_device(W, H, rank, world, [staging[k][f].data_ptr() for f in range(nb)])
+                for f in range(nb):
+                    host.gather_frame(staging[k][f], W, H,
+                                      lambda g, k=k, f=f: (r.untile_device(W, H, world, g.data_ptr(), out[k][f].data_ptr()), out[k][f])[1],
+                                      gathered[k][f])
+        step.total = 0
 
     def fence():
         if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
+    if multi:
+        step.total = args.warmup
     for i in range(args.warmup):
         step(i)
     fence()
+    if multi:
+        step.total = args.steps
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record(stream)
@@ -182,7 +200,7 @@ def main():
         if not multi:
             kms.append(r.render_frame_device(W, H, frame.data_ptr(), stats=True)["kernel_ms"])
         else:
-            kms.append(r.render_tiles_device(W, H, rank, world, staging[0].data_ptr(), stats=True)["kernel_ms"])
+            kms.append(r.render_tiles_device(W, H, rank, world, staging[0][0].data_ptr(), stats=True)["kernel_ms"])
     kernel_ms = float(np.median(kms))
 
     # PCIe-inclusive variant (host output buffer handed over the C ABI), for DESIGN.md; never `value`
@@ -208,7 +226,7 @@ def main():
                                        "heightfield5m": "seeded height field 1581x1581 quads + ground quad",
                                        "soup": "seeded soup of 3125 copied icospheres + ground quad"}[args.scene], n_tris, W, H, len(sc["lights"])),
                        "rays_per_frame": rays_per_frame, "primary_rays": cnt["rays_primary"], "shadow_rays": cnt["rays_shadow"],
-                       "frames_in_flight": n_fly,
+                       "frames_in_flight": n_fly * batch, "launches_in_flight": n_fly, "frames_per_launch": batch,
                        "parallelism": "1 GPU, one launch per frame" if world == 1 else "framebuffer tiles 16x16 round-robin over %d GPUs + 1 RCCL all-gather/frame" % world,
                        "bvh": {"nodes": r.bvh_info()["n_nodes"], "max_depth": r.bvh_info()["max_depth"], "build_and_upload_s": upload_s}},
             "ms_per_frame": ms_per_step,

@@ -35,7 +35,8 @@ SHADE_DTYPE = np.dtype([("n0", "f4", 3), ("n1", "f4", 3), ("n2", "f4", 3), ("mat
 ABI_SYMBOLS = [
     "crt_abi_version", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_textures", "crt_bvh_export_uv", "crt_set_camera",
     "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_set_option", "crt_debug_read_timeline", "crt_debug_read_counters", "crt_render_frame", "crt_render_frame_device",
-    "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_untile_device", "crt_set_stream", "crt_reset_stream",
+    "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_render_frames_batch_device", "crt_render_tiles_batch_device",
+    "crt_untile_device", "crt_set_stream", "crt_reset_stream",
     "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_build_host4", "crt_build_stats",
     "crt_scene_load", "crt_scene_save", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
     "crt_scene_add_material", "crt_scene_mesh_count", "crt_scene_mesh", "crt_scene_light_count", "crt_scene_light",
@@ -134,6 +135,8 @@ def lib():
         "crt_tile_count": (u32, [u32, u32]),
         "crt_tile_slots": (u32, [u32, u32, u32]),
         "crt_render_tiles_device": (C.c_int, [vp, u32, u32, u32, u32, vp, vp]),
+        "crt_render_frames_batch_device": (C.c_int, [vp, u32, u32, u32, vp, vp, vp]),
+        "crt_render_tiles_batch_device": (C.c_int, [vp, u32, u32, u32, u32, u32, vp, vp, vp]),
         "crt_untile_device": (C.c_int, [vp, u32, u32, u32, vp, vp]),
         "crt_set_stream": (C.c_int, [vp, vp]),
         "crt_reset_stream": (C.c_int, [vp]),
@@ -632,6 +635,31 @@ class Renderer:
         st = FrameStats() if stats else None
         self._ok(lib().crt_render_tiles_device(self.h, w, h, rank, n_ranks, d_staging, C.byref(st) if stats else None),
                  "crt_render_tiles_device")
+        return st.as_dict() if stats else None
+
+    @staticmethod
+    def _batch_args(cameras, d_out):
+        n = len(d_out)
+        outs = (C.c_void_p * n)(*[int(x) for x in d_out])
+        cams = None
+        if cameras is not None:
+            cams = np.ascontiguousarray(np.concatenate([np.concatenate([_f32(p, 3), _f32(r, 9)]) for p, r in cameras]), dtype=np.float32)
+            assert cams.size == 12 * n
+        return n, cams, outs
+
+    def render_frames_batch_device(self, w, h, d_rgba8_list, cameras=None, stats=False):
+        """several frames in ONE launch; cameras = [(pos, rot3x3), ...] per frame or None (current camera for all)."""
+        n, cams, outs = self._batch_args(cameras, d_rgba8_list)
+        st = FrameStats() if stats else None
+        self._ok(lib().crt_render_frames_batch_device(self.h, w, h, n, cams.ctypes.data if cams is not None else None, outs,
+                                                      C.byref(st) if stats else None), "crt_render_frames_batch_device")
+        return st.as_dict() if stats else None
+
+    def render_tiles_batch_device(self, w, h, rank, n_ranks, d_staging_list, cameras=None, stats=False):
+        n, cams, outs = self._batch_args(cameras, d_staging_list)
+        st = FrameStats() if stats else None
+        self._ok(lib().crt_render_tiles_batch_device(self.h, w, h, rank, n_ranks, n, cams.ctypes.data if cams is not None else None, outs,
+                                                     C.byref(st) if stats else None), "crt_render_tiles_batch_device")
         return st.as_dict() if stats else None
 
     def untile_device(self, w, h, n_ranks, d_gathered, d_frame):

@@ -186,6 +186,8 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     // optimum (28 and 32 resident wavefronts are 5-10 % slower: L1 thrash); deeper entries (never seen on the test scenes,
     // possible up to the builder's depth 32) spill to the arena
     p.stack_entries = c->tuneStackEntries ? c->tuneStackEntries : 24u;
+    p.n_batch = 1;
+    p.units_per_frame = crt::renderUnitCount(p);
 }
 
 // enqueue one frame; when stats != nullptr, bracket with events, synchronise and fill the timers/counters
@@ -193,7 +195,7 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
 {
     const bool counting = c->counting;
     if (counting) HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 16 * sizeof(unsigned long long), c->stream));
-    if (c->wantTimeline) {
+    if (c->wantTimeline && p.n_batch == 1) {
         const size_t words = 3 * (static_cast<size_t>(p.tiles_x + 4) * (p.tiles_y + 4) * 4 + 1024);
         if (c->timelineWords < words) {
             if (c->dTimeline) (void)hipFree(c->dTimeline);
@@ -209,7 +211,7 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         // deepest stack a ray can build: three pending siblings per wide level; what does not fit the LDS part spills
         const uint32_t deepest = 3u * c->bvh.depth4 + 1u;
         p.spill_stride = deepest > p.stack_entries ? deepest - p.stack_entries : 1u;
-        const size_t need = static_cast<size_t>(crt::renderUnitCount(p)) * 64u * p.spill_stride * sizeof(int);
+        const size_t need = static_cast<size_t>(crt::renderUnitCount(p)) * p.n_batch * 64u * p.spill_stride * sizeof(int);
         if (c->spillBytes[slot] < need) {
             HIP_TRY(c, hipDeviceSynchronize());
             if (c->dSpill[slot]) (void)hipFree(c->dSpill[slot]);
@@ -721,6 +723,52 @@ int crt_render_tiles_device(crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, u
     if (rc) return rc;
     if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return CRT_OK;
+}
+
+namespace {
+// shared by the two batch entry points: frame 0 takes the place of the single frame, the others go to the batch arrays
+int runBatch(crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_t n_ranks, bool staging, uint32_t n_frames, const float* cameras,
+             void* const* d_out, crt_frame_stats* stats)
+{
+    int rc = checkRenderable(c, w, h);
+    if (rc) return rc;
+    if (n_frames == 0 || n_frames > static_cast<uint32_t>(crt::kMaxBatch)) return fail(c, CRT_EINVAL, "n_frames %u outside [1,%d]", n_frames, crt::kMaxBatch);
+    if (!d_out || n_ranks == 0 || rank >= n_ranks) return fail(c, CRT_EINVAL, "bad batch arguments (rank %u of %u)", rank, n_ranks);
+    for (uint32_t f = 0; f < n_frames; f++)
+        if (!d_out[f]) return fail(c, CRT_EINVAL, "output pointer of frame %u is NULL", f);
+    const auto t0 = std::chrono::steady_clock::now();
+    RenderParams p;
+    fillParams(c, w, h, rank, n_ranks, p);
+    p.staging = staging ? 1u : 0u;
+    p.n_batch = n_frames;
+    p.rgba8 = static_cast<uint32_t*>(d_out[0]);
+    if (cameras) {
+        std::memcpy(p.pos, cameras, sizeof(p.pos));
+        std::memcpy(p.rot, cameras + 3, sizeof(p.rot));
+    }
+    for (uint32_t f = 1; f < n_frames; f++) {
+        const float* cam = cameras ? cameras + 12 * f : nullptr;
+        std::memcpy(p.batch_pos[f - 1], cam ? cam : c->pos, sizeof(p.pos));
+        std::memcpy(p.batch_rot[f - 1], cam ? cam + 3 : c->rot, sizeof(p.rot));
+        p.batch_rgba8[f - 1] = static_cast<uint32_t*>(d_out[f]);
+    }
+    rc = runRender(c, p, stats);
+    if (rc) return rc;
+    if (stats) stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return CRT_OK;
+}
+} // namespace
+
+int crt_render_frames_batch_device(crt_ctx* c, uint32_t w, uint32_t h, uint32_t n_frames, const float* cameras, void* const* d_rgba8,
+                                   crt_frame_stats* stats)
+{
+    return runBatch(c, w, h, 0, 1, false, n_frames, cameras, d_rgba8, stats);
+}
+
+int crt_render_tiles_batch_device(crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_t n_ranks, uint32_t n_frames,
+                                  const float* cameras, void* const* d_staging, crt_frame_stats* stats)
+{
+    return runBatch(c, w, h, rank, n_ranks, true, n_frames, cameras, d_staging, stats);
 }
 
 int crt_untile_device(crt_ctx* c, uint32_t w, uint32_t h, uint32_t n_ranks, const void* d_gathered, void* d_rgba8)

@@ -7,6 +7,7 @@ struct ihipStream_t;
 
 namespace crt {
 
+constexpr int kMaxBatch = 4;       // frames per launch (crt_render_tiles_batch_device)
 constexpr int kTile = 16;          // macro tile edge: one 256-thread workgroup = 4 wavefronts of 8x8 pixels
 constexpr int kStackEntries = 32;  // upper bound of the per-lane LDS traversal stack = kMaxDepth of the builder
 
@@ -50,6 +51,13 @@ struct RenderParams {
     uint32_t spill_stride;        // >= 3 * wide depth + 1 - stack_entries: the deepest stack any ray can build
     const uint32_t* unit_order;   // nullable: work units sorted by descending cost of the previous frame (launch order)
     uint32_t* unit_cost;          // nullable: per work unit, traversal-loop iterations of its wavefront (this frame)
+    // batch: n_batch frames (1..kMaxBatch) in ONE launch, grid = n_batch x units_per_frame; frame 0 uses pos / rot / rgba8
+    // above, frame f > 0 its own camera and output below (hit ids / float colour are frame 0's only)
+    uint32_t n_batch;
+    uint32_t units_per_frame;
+    float batch_pos[3][3];
+    float batch_rot[3][9];
+    uint32_t* batch_rgba8[3];
     unsigned long long* timeline; // counting variant only, nullable: per workgroup {start, end} of s_memrealtime (100 MHz) + XCC id
 };
 

@@ -808,13 +808,13 @@ __device__ __forceinline__ float rngNext(uint32_t& st)
 }
 
 template <bool COUNT, int BLOCK>
-__device__ __forceinline__ F3 tracePath(const RenderParams& p, const float4* nodes, const float4* tris, uint32_t px, uint32_t py,
+__device__ __forceinline__ F3 tracePath(const RenderParams& p, const float* camPos, const float* camRot, const float4* nodes, const float4* tris, uint32_t px, uint32_t py,
                                         uint32_t pix, uint32_t sample, Stack& stack, Hit& firstHit, uint32_t& iters,
                                         uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow, uint32_t& cntClosest)
 {
     uint32_t rng = pcgHash(pix ^ pcgHash(sample + pcgHash(p.seed)));
     const float jx = rngNext(rng), jy = rngNext(rng);
-    Ray r = makeRay(f3(p.pos[0], p.pos[1], p.pos[2]), rayDirJ(p.rot, px, py, jx, jy, static_cast<float>(p.width), static_cast<float>(p.height)));
+    Ray r = makeRay(f3(camPos[0], camPos[1], camPos[2]), rayDirJ(camRot, px, py, jx, jy, static_cast<float>(p.width), static_cast<float>(p.height)));
     F3 L = f3(0.0f, 0.0f, 0.0f), thr = f3(1.0f, 1.0f, 1.0f);
     const F3 miss = f3(p.miss[0], p.miss[1], p.miss[2]);
     float tmin = kTMin;
@@ -901,7 +901,16 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
     //  * otherwise: workgroup b runs on XCD b % 8 (observed round-robin dispatch); groups of xcd_group consecutive tiles
     //    of the list are dealt round-robin to the XCDs so all XCDs sweep the frame together.
     // Either way this is scheduling only: results never depend on it.
-    const uint32_t b = blockIdx.x;
+    // several frames in one launch (throughput mode): a launch's critical path -- its slowest packet -- is then shared by the
+    // whole batch; workgroup index = frame * units_per_frame + position
+    uint32_t b = blockIdx.x, frame = 0;
+    while (frame + 1u < p.n_batch && b >= p.units_per_frame) {
+        b -= p.units_per_frame;
+        frame++;
+    }
+    const float* camPos = frame ? p.batch_pos[frame - 1u] : p.pos;
+    const float* camRot = frame ? p.batch_rot[frame - 1u] : p.rot;
+    uint32_t* outRgba8 = frame ? p.batch_rgba8[frame - 1u] : p.rgba8;
     uint32_t unit;
     if (p.unit_order) {
         unit = p.unit_order[b];
@@ -932,7 +941,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
         tile_y = k / p.tiles_x;
     }
     if (!valid) {
-        if (p.unit_cost && threadIdx.x == 0) p.unit_cost[unit] = 0;
+        if (p.unit_cost && frame == 0u && threadIdx.x == 0) p.unit_cost[unit] = 0;
         return;
     }
 
@@ -952,7 +961,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
         const float4* tris = reinterpret_cast<const float4*>(p.tris);
         Stack stack;
         stack.lds = s_stack + tid;
-        stack.spill = p.spill + (static_cast<size_t>(unit) * 64u + tid) * p.spill_stride;
+        stack.spill = p.spill + ((static_cast<size_t>(frame) * p.units_per_frame + unit) * 64u + tid) * p.spill_stride;
         stack.cap = static_cast<int>(p.stack_entries);
         stack.sp = 0;
 
@@ -966,14 +975,14 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
             F3 acc = f3(0.0f, 0.0f, 0.0f);
             h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
             for (uint32_t sm = 0; sm < p.spp; sm++) {
-                const F3 Ls = tracePath<COUNT, BLOCK>(p, nodes, tris, px, py, pixId, sm, stack, h, iters, cntNodes, cntTris, cntShadow, cntClosest);
+                const F3 Ls = tracePath<COUNT, BLOCK>(p, camPos, camRot, nodes, tris, px, py, pixId, sm, stack, h, iters, cntNodes, cntTris, cntShadow, cntClosest);
                 acc = f3(acc.x + Ls.x, acc.y + Ls.y, acc.z + Ls.z);
             }
             const float inv = 1.0f / static_cast<float>(p.spp);
             col = f3(acc.x * inv, acc.y * inv, acc.z * inv);
         } else {
-            const F3 o = f3(p.pos[0], p.pos[1], p.pos[2]);
-            const Ray r = makeRay(o, rayDir(p.rot, px, py, static_cast<float>(p.width), static_cast<float>(p.height)));
+            const F3 o = f3(camPos[0], camPos[1], camPos[2]);
+            const Ray r = makeRay(o, rayDir(camRot, px, py, static_cast<float>(p.width), static_cast<float>(p.height)));
             if (COUNT) cntClosest++;
             traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, iters, cntNodes, cntTris);
             col = f3(p.miss[0], p.miss[1], p.miss[2]); // miss shader (hlsl:72-76)
@@ -995,12 +1004,12 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
 #endif
         const uint32_t packed = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
         const size_t pix = static_cast<size_t>(py) * p.width + px;
-        if (p.staging) p.rgba8[static_cast<size_t>((tile_y * p.tiles_x + tile_x) / p.n_ranks) * (kTile * kTile) + ly * kTile + lx] = packed;
-        else p.rgba8[pix] = packed;
-        if (p.hit_inst) p.hit_inst[pix] = inst;
-        if (p.hit_prim) p.hit_prim[pix] = prim;
-        if (p.hit_t) p.hit_t[pix] = hit ? h.t : kTMax;
-        if (p.rgb_f32) {
+        if (p.staging) outRgba8[static_cast<size_t>((tile_y * p.tiles_x + tile_x) / p.n_ranks) * (kTile * kTile) + ly * kTile + lx] = packed;
+        else outRgba8[pix] = packed;
+        if (p.hit_inst && frame == 0u) p.hit_inst[pix] = inst;
+        if (p.hit_prim && frame == 0u) p.hit_prim[pix] = prim;
+        if (p.hit_t && frame == 0u) p.hit_t[pix] = hit ? h.t : kTMax;
+        if (p.rgb_f32 && frame == 0u) {
             p.rgb_f32[3 * pix + 0] = col.x;
             p.rgb_f32[3 * pix + 1] = col.y;
             p.rgb_f32[3 * pix + 2] = col.z;
@@ -1008,7 +1017,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
     }
     // cost fed back to order the next frame = this wavefront's lifetime in 0.64 us units (constant 100 MHz clock): it
     // sees what an iteration count does not (distant, incoherent packets are slow per iteration: cache misses)
-    if (p.unit_cost && threadIdx.x == 0) p.unit_cost[unit] = static_cast<uint32_t>((__builtin_amdgcn_s_memrealtime() - t_start) >> 6);
+    if (p.unit_cost && frame == 0u && threadIdx.x == 0) p.unit_cost[unit] = static_cast<uint32_t>((__builtin_amdgcn_s_memrealtime() - t_start) >> 6);
     if (p.timeline && threadIdx.x == 0) {
         // diagnostic build only: wave lifetime on the constant 100 MHz clock, and which XCD ran it
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
@@ -1068,7 +1077,7 @@ int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream)
     if (p.n_local_tiles == 0) return 0;
     // list length: single GPU walks whole 4x4-tile blocks (padded at the frame edges); then padded to 8 XCDs x kGroupMax
     const uint32_t n = renderUnitCount(p) / 4u;
-    const dim3 grid(n * 4u), block(64);
+    const dim3 grid(n * 4u * (p.n_batch ? p.n_batch : 1u)), block(64);
     const size_t lds = static_cast<size_t>(p.stack_entries) * 64u * sizeof(int);
     if (p.mode >= 200u) {
         if (counting) hipLaunchKernelGGL((renderKernel<true, true>), grid, block, lds, stream, p);

@@ -156,6 +156,17 @@ uint32_t crt_tile_count(uint32_t width, uint32_t height);
 uint32_t crt_tile_slots(uint32_t width, uint32_t height, uint32_t n_ranks); /* ceil(tile_count / n_ranks) */
 int crt_render_tiles_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t rank, uint32_t n_ranks,
                             void* d_staging_rgba8 /* slots*256*4 bytes */, crt_frame_stats* stats);
+/* Throughput mode (no reference counterpart: DXRTRenderer::renderFrame issues one DispatchRays per call, R/DXRTRenderer.cpp:1348-1350):
+ * n_frames (1..4) frames of the current scene, mode and size in ONE launch.  A launch lasts as long as its slowest 8x8 packet
+ * (a grazing ray walks hundreds of dependent steps); a batch shares that critical path, which is what bounds an N-GPU tile
+ * share (1/N of the work, same critical path).  cameras = n_frames x 12 floats {pos[3], rot3x3_rowmajor[9]} or NULL (the
+ * current camera for every frame); d_rgba8[f] / d_staging[f] = frame f's output, laid out as in crt_render_frame_device /
+ * crt_render_tiles_device.  Frames are independent: each equals what a single-frame call with its camera renders. */
+int crt_render_frames_batch_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_frames, const float* cameras,
+                                   void* const* d_rgba8, crt_frame_stats* stats);
+int crt_render_tiles_batch_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t rank, uint32_t n_ranks, uint32_t n_frames,
+                                  const float* cameras, void* const* d_staging, crt_frame_stats* stats);
+
 /* De-interleave a gathered buffer (n_ranks * slots * 1024 bytes, rank-major) into a row-major frame. */
 int crt_untile_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_ranks,
                       const void* d_gathered, void* d_rgba8_rowmajor);

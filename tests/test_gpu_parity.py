@@ -545,3 +545,58 @@ def test_frames_in_flight_and_launch_order_feedback(pkg, oracle, scenes, dragon,
         torch.cuda.synchronize()
         renderer.set_option("adaptive_order", 2)
         renderer.reset_stream()
+
+
+def test_batch_launch_equals_single_frames(pkg, oracle, scenes, dragon, renderer):
+    """crt_render_frames_batch_device / crt_render_tiles_batch_device: several frames (own camera each) in one launch are
+    exactly the frames single launches with those cameras give -- full frames against the oracle, tile shares against the
+    single-frame tile call; argument errors are reported."""
+    import torch
+    sc = _with_normals(scenes, dragon)
+    cam = sc["camera"]
+    renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    w, h = 333, 217
+    pos0 = np.float32(cam["position"])
+    cams = [(pos0 + np.float32([0.7 * k, 0.1 * k, -0.4 * k]), scenes.camera_matrix(yaw_deg=4.0 * k, pitch_deg=-2.0 * k)) for k in range(4)]
+    for mode in (100, pkg.MODE_PATH):
+        renderer.change_shading_mode(mode)
+        refs = [O.render(p, r, mode, w, h)["rgba8"].reshape(-1, 4).copy().view(np.uint32).ravel() for p, r in cams]
+        for n in (1, 2, 3, 4):
+            bufs = [torch.full((w * h,), 0x7E57AB1E, dtype=torch.int32, device="cuda") for _ in range(n)]
+            torch.cuda.synchronize()
+            st = renderer.render_frames_batch_device(w, h, [b.data_ptr() for b in bufs], cams[:n], stats=True)
+            assert st["kernel_ms"] > 0
+            for k, b in enumerate(bufs):
+                assert np.array_equal(b.cpu().numpy().view(np.uint32), refs[k]), "mode %d batch of %d, frame %d" % (mode, n, k)
+    # tile shares: batch == single-frame calls with the same cameras (n_ranks 3, every rank)
+    renderer.change_shading_mode(100)
+    slots = pkg.tile_slots(w, h, 3)
+    for rank in range(3):
+        single = []
+        for p, r in cams[:3]:
+            renderer.set_camera(p, r)
+            s1 = torch.zeros(slots * 256, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            renderer.render_tiles_device(w, h, rank, 3, s1.data_ptr(), stats=True)
+            single.append(s1)
+        batch = [torch.zeros(slots * 256, dtype=torch.int32, device="cuda") for _ in range(3)]
+        torch.cuda.synchronize()
+        renderer.render_tiles_batch_device(w, h, rank, 3, [b.data_ptr() for b in batch], cams[:3], stats=True)
+        for k in range(3):
+            assert torch.equal(batch[k], single[k]), (rank, k)
+    # cameras=None: every frame uses the current camera
+    renderer.set_camera(*cams[1])
+    two = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    renderer.render_frames_batch_device(w, h, [b.data_ptr() for b in two], None, stats=True)
+    assert torch.equal(two[0], two[1]) and np.array_equal(two[0].cpu().numpy().view(np.uint32), refs_for(O, cams[1], w, h))
+    with pytest.raises(pkg.CrtError):
+        renderer.render_frames_batch_device(w, h, [two[0].data_ptr()] * 5)
+    with pytest.raises(pkg.CrtError):
+        renderer.render_frames_batch_device(w, h, [two[0].data_ptr(), 0])
+    renderer.set_camera(cam["position"], cam["matrix"])
+
+
+def refs_for(O, cam, w, h):
+    return O.render(cam[0], cam[1], 100, w, h)["rgba8"].reshape(-1, 4).copy().view(np.uint32).ravel()

@@ -14,14 +14,16 @@ pkg = e.load_package(); scenes = importlib.import_module(e.PKG_NAME + ".scenes")
 sc = scenes.heightfield(n_lights=1)
 r = pkg.Renderer(0); r.upload(sc["meshes"], sc["lights"], sc["materials"]); r.set_camera(sc["camera"]["position"], sc["camera"]["matrix"]); r.change_shading_mode(100)
 W, H = 1920, 1080
-n_fly = 4
+n_fly = int(os.environ.get('NFLY', '4'))
+BATCH = int(os.environ.get('BATCH', '1'))
 streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_fly - 1)]
 import statistics
-for N, adaptive in ((1, 2), (1, 1), (1, 0), (2, 1), (2, 0), (4, 1), (4, 0), (8, 1), (8, 0)):
+for N, adaptive in ((1, 2), (2, 2), (4, 2), (8, 2)):
     r.set_option("adaptive_order", adaptive)
     share = host.rank_share(W, H, 0, N)
-    staging = [torch.zeros(share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
-    gathered = [torch.zeros(N * share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
+    PAD = 64  # room for experimental ownership layouts
+    staging = [torch.zeros((share["slots"] + PAD) * 256, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
+    gathered = [torch.zeros(N * (share["slots"] + PAD) * 256, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
     frames = [torch.zeros(W * H, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
     r.set_stream(streams[0].cuda_stream)
     for _ in range(5): r.render_tiles_device(W, H, 0, N, staging[0].data_ptr(), stats=True)
@@ -32,11 +34,15 @@ for N, adaptive in ((1, 2), (1, 1), (1, 0), (2, 1), (2, 0), (4, 1), (4, 0), (8, 
             k = i % n_fly
             r.set_stream(streams[k].cuda_stream)
             with torch.cuda.stream(streams[k]):
-                r.render_tiles_device(W, H, 0, N, staging[k].data_ptr())
-                if what != "render":
-                    dist.all_gather_into_tensor(gathered[k][:staging[k].numel()], staging[k])
-                if what.endswith("untile"):
-                    r.untile_device(W, H, N, gathered[k].data_ptr(), frames[k].data_ptr())
+                if BATCH == 1:
+                    r.render_tiles_device(W, H, 0, N, staging[k].data_ptr())
+                else:
+                    r.render_tiles_batch_device(W, H, 0, N, [staging[k].data_ptr()] * BATCH)  # same buffer: timing only
+                for _ in range(BATCH):
+                    if what != "render":
+                        dist.all_gather_into_tensor(gathered[k][:staging[k].numel()], staging[k])
+                    if what.endswith("untile"):
+                        r.untile_device(W, H, N, gathered[k].data_ptr(), frames[k].data_ptr())
         for i in range(40): step(i)
         torch.cuda.synchronize()
         K = 400
@@ -45,6 +51,6 @@ for N, adaptive in ((1, 2), (1, 1), (1, 0), (2, 1), (2, 0), (4, 1), (4, 0), (8, 
         t1 = time.perf_counter()
         torch.cuda.synchronize()
         t2 = time.perf_counter()
-        print("N=%d %-22s issue %.1f us/step   throughput %.1f us/step" % (N, what, (t1 - t0) / K * 1e6, (t2 - t0) / K * 1e6), flush=True)
+        print("N=%d %-22s issue %.1f us/frame   throughput %.1f us/frame (batch %d)" % (N, what, (t1 - t0) / K / BATCH * 1e6, (t2 - t0) / K / BATCH * 1e6, BATCH), flush=True)
 r.set_stream(streams[0].cuda_stream)
 dist.destroy_process_group()
