@@ -902,12 +902,11 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
     //    of the list are dealt round-robin to the XCDs so all XCDs sweep the frame together.
     // Either way this is scheduling only: results never depend on it.
     // several frames in one launch (throughput mode): a launch's critical path -- its slowest packet -- is then shared by the
-    // whole batch; workgroup index = frame * units_per_frame + position
-    uint32_t b = blockIdx.x, frame = 0;
-    while (frame + 1u < p.n_batch && b >= p.units_per_frame) {
-        b -= p.units_per_frame;
-        frame++;
-    }
+    // whole batch; workgroup index = position * n_batch + frame
+    // (position-major: the b-th work units of all frames are neighbours in the launch, so with a cost-sorted order the
+    // expensive packets of every frame of the batch start first)
+    const uint32_t frame = p.n_batch > 1u ? blockIdx.x % p.n_batch : 0u;
+    const uint32_t b = p.n_batch > 1u ? blockIdx.x / p.n_batch : blockIdx.x;
     const float* camPos = frame ? p.batch_pos[frame - 1u] : p.pos;
     const float* camRot = frame ? p.batch_rot[frame - 1u] : p.rot;
     uint32_t* outRgba8 = frame ? p.batch_rgba8[frame - 1u] : p.rgba8;
