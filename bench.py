@@ -79,7 +79,7 @@ def main():
                     "N=1 (launches back to back on ONE stream, so the HIP events over the timed region measure the kernel's average "
                     "launch duration and the rocprofv3 summary of the same command agrees with it), 4 at N>1 (the tail of one "
                     "rank's tile launch and the all-gather overlap the next frame)")
-    ap.add_argument("--batch", type=int, default=2, help="N>1 only: frames per launch (1..4) of each rank's tile share")
+    ap.add_argument("--batch", type=int, default=0, help="N>1 only: frames per launch (1..4) of each rank's tile share; 0 = 2 from 8 ranks up, else 1")
     ap.add_argument("--force-dist", action="store_true", help="rehearse the N>1 code path (RCCL init, tile staging, all-gather, "
                     "de-interleave) with whatever world size the launcher gives, even 1")
     args = ap.parse_args()
@@ -121,7 +121,9 @@ def main():
     r.set_camera(cam["position"], cam["matrix"])
     r.change_shading_mode(MODE)
     n_fly = args.inflight if args.inflight > 0 else (4 if multi else 1)
-    batch = max(1, min(4, args.batch)) if multi else 1
+    # frames per launch at N > 1: a 1/8 share is bound by the launch's slowest packet, which a batch shares (66 -> 50 us per
+    # frame measured for an 8-rank share); shares of 1/2 and 1/4 are not (no gain measured)
+    batch = (max(1, min(4, args.batch)) if args.batch > 0 else (2 if world >= 8 else 1)) if multi else 1
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(n_fly - 1)]
     stream = streams[0]
     r.set_stream(stream.cuda_stream)  # the kernels run on torch streams: torch events and RCCL order with them
@@ -144,8 +146,10 @@ def main():
         # N > 1: each launch carries `batch` consecutive frames of this rank's tile share (crt_render_tiles_batch_device): a
         # launch lasts as long as its slowest packet, and a 1/N share has the same slowest packet as the whole frame
         share = host.rank_share(W, H, rank, world)
-        staging = [[torch.zeros(share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(batch)] for _ in range(n_fly)]
-        gathered = [[torch.zeros(world * share["slots"] * 256, dtype=torch.int32, device="cuda") for _ in range(batch)] for _ in range(n_fly)]
+        # one contiguous staging / gathered buffer per launch slot: the batch travels in ONE all-gather ([rank][frame][slot])
+        per = share["slots"] * 256
+        staging = [torch.zeros(batch * per, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
+        gathered = [torch.zeros(world * batch * per, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
         out = [[torch.zeros(W * H, dtype=torch.int32, device="cuda") for _ in range(batch)] for _ in range(n_fly)]
         launches = [0]
 
@@ -158,11 +162,10 @@ def main():
             launches[0] += 1
             r.set_stream(streams[k].cuda_stream)
             with torch.cuda.stream(streams[k]):
-                r.render_tiles_batch_device(W, H, rank, world, [staging[k][f].data_ptr() for f in range(nb)])
-                for f in range(nb):
-                    host.gather_frame(staging[k][f], W, H,
-                                      lambda g, k=k, f=f: (r.untile_device(W, H, world, g.data_ptr(), out[k][f].data_ptr()), out[k][f])[1],
-                                      gathered[k][f])
+                r.render_tiles_batch_device(W, H, rank, world, [staging[k].data_ptr() + 4 * per * f for f in range(nb)])
+                host.gather_batch(staging[k][:nb * per], W, H, nb,
+                                  lambda g, f, k=k, nb=nb: (r.untile_batch_device(W, H, world, nb, f, g.data_ptr(), out[k][f].data_ptr()), out[k][f])[1],
+                                  gathered[k][:world * nb * per])
         step.total = 0
 
     def fence():
@@ -200,7 +203,7 @@ def main():
         if not multi:
             kms.append(r.render_frame_device(W, H, frame.data_ptr(), stats=True)["kernel_ms"])
         else:
-            kms.append(r.render_tiles_device(W, H, rank, world, staging[0][0].data_ptr(), stats=True)["kernel_ms"])
+            kms.append(r.render_tiles_device(W, H, rank, world, staging[0].data_ptr(), stats=True)["kernel_ms"])
     kernel_ms = float(np.median(kms))
 
     # PCIe-inclusive variant (host output buffer handed over the C ABI), for DESIGN.md; never `value`

@@ -36,7 +36,7 @@ ABI_SYMBOLS = [
     "crt_abi_version", "crt_create", "crt_destroy", "crt_last_error", "crt_upload_scene", "crt_set_textures", "crt_bvh_export_uv", "crt_set_camera",
     "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_set_option", "crt_debug_read_timeline", "crt_debug_read_counters", "crt_render_frame", "crt_render_frame_device",
     "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_render_frames_batch_device", "crt_render_tiles_batch_device",
-    "crt_untile_device", "crt_set_stream", "crt_reset_stream",
+    "crt_untile_device", "crt_untile_batch_device", "crt_set_stream", "crt_reset_stream",
     "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_build_host4", "crt_build_stats",
     "crt_scene_load", "crt_scene_save", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
     "crt_scene_add_material", "crt_scene_mesh_count", "crt_scene_mesh", "crt_scene_light_count", "crt_scene_light",
@@ -135,6 +135,7 @@ def lib():
         "crt_tile_count": (u32, [u32, u32]),
         "crt_tile_slots": (u32, [u32, u32, u32]),
         "crt_render_tiles_device": (C.c_int, [vp, u32, u32, u32, u32, vp, vp]),
+        "crt_untile_batch_device": (C.c_int, [vp, u32, u32, u32, u32, u32, vp, vp]),
         "crt_render_frames_batch_device": (C.c_int, [vp, u32, u32, u32, vp, vp, vp]),
         "crt_render_tiles_batch_device": (C.c_int, [vp, u32, u32, u32, u32, u32, vp, vp, vp]),
         "crt_untile_device": (C.c_int, [vp, u32, u32, u32, vp, vp]),
@@ -201,11 +202,12 @@ def tile_slots(w, h, n_ranks):
     return (tile_count(w, h) + n_ranks - 1) // n_ranks
 
 
-def untile_host(gathered, w, h, n_ranks):
+def untile_host(gathered, w, h, n_ranks, n_frames=1, frame=0):
     """numpy statement of the tile-major -> row-major de-interleave (crt_untile_device's layout contract):
-    gathered = uint32[n_ranks, slots, 16, 16]; macro tile k (row-major) lives at rank k % n_ranks, slot k // n_ranks."""
+    gathered = uint32[n_ranks, n_frames, slots, 16, 16]; macro tile k (row-major) of frame f lives at rank k % n_ranks,
+    frame f, slot k // n_ranks (n_frames = 1: one frame per all-gather)."""
     slots = tile_slots(w, h, n_ranks)
-    g = np.asarray(gathered, dtype=np.uint32).reshape(n_ranks, slots, TILE, TILE)
+    g = np.asarray(gathered, dtype=np.uint32).reshape(n_ranks, n_frames, slots, TILE, TILE)[:, frame]
     tx, ty = (w + TILE - 1) // TILE, (h + TILE - 1) // TILE
     k = np.arange(tx * ty)
     tiles = g[k % n_ranks, k // n_ranks]                       # [k, 16, 16]
@@ -661,6 +663,9 @@ class Renderer:
         self._ok(lib().crt_render_tiles_batch_device(self.h, w, h, rank, n_ranks, n, cams.ctypes.data if cams is not None else None, outs,
                                                      C.byref(st) if stats else None), "crt_render_tiles_batch_device")
         return st.as_dict() if stats else None
+
+    def untile_batch_device(self, w, h, n_ranks, n_frames, frame, d_gathered, d_frame):
+        self._ok(lib().crt_untile_batch_device(self.h, w, h, n_ranks, n_frames, frame, d_gathered, d_frame), "crt_untile_batch_device")
 
     def untile_device(self, w, h, n_ranks, d_gathered, d_frame):
         self._ok(lib().crt_untile_device(self.h, w, h, n_ranks, d_gathered, d_frame), "crt_untile_device")

@@ -771,14 +771,22 @@ int crt_render_tiles_batch_device(crt_ctx* c, uint32_t w, uint32_t h, uint32_t r
     return runBatch(c, w, h, rank, n_ranks, true, n_frames, cameras, d_staging, stats);
 }
 
-int crt_untile_device(crt_ctx* c, uint32_t w, uint32_t h, uint32_t n_ranks, const void* d_gathered, void* d_rgba8)
+int crt_untile_batch_device(crt_ctx* c, uint32_t w, uint32_t h, uint32_t n_ranks, uint32_t n_frames, uint32_t frame, const void* d_gathered,
+                            void* d_rgba8)
 {
     if (!c) return CRT_EINVAL;
-    if (!d_gathered || !d_rgba8 || n_ranks == 0 || w == 0 || h == 0) return fail(c, CRT_EINVAL, "crt_untile_device: bad argument");
+    if (!d_gathered || !d_rgba8 || n_ranks == 0 || w == 0 || h == 0 || n_frames == 0 || frame >= n_frames)
+        return fail(c, CRT_EINVAL, "crt_untile_batch_device: bad argument");
+    const uint32_t slots = crt_tile_slots(w, h, n_ranks);
     const int rc = crt::launchUntile(static_cast<const uint32_t*>(d_gathered), static_cast<uint32_t*>(d_rgba8), w, h, n_ranks,
-                                     crt_tile_slots(w, h, n_ranks), c->stream);
+                                     n_frames * slots, frame * slots, c->stream);
     if (rc != 0) return fail(c, CRT_EHIP, "untile kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
     return CRT_OK;
+}
+
+int crt_untile_device(crt_ctx* c, uint32_t w, uint32_t h, uint32_t n_ranks, const void* d_gathered, void* d_rgba8)
+{
+    return crt_untile_batch_device(c, w, h, n_ranks, 1, 0, d_gathered, d_rgba8);
 }
 
 int crt_bvh_info(const crt_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* max_depth)

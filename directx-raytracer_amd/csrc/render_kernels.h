@@ -69,7 +69,7 @@ uint32_t renderUnitCount(const RenderParams& p);
 int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, ihipStream_t* stream);
 // tile-major gathered buffer -> row-major frame
 int launchUntile(const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height, uint32_t n_ranks,
-                 uint32_t slots, ihipStream_t* stream);
+                 uint32_t rank_stride, uint32_t first_slot, ihipStream_t* stream);
 
 // device-side texture record (crt_texture with the pixel pointer replaced by an offset into the texel pool)
 struct TextureRec {

@@ -1050,14 +1050,16 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
 
 __global__ __launch_bounds__(kBlock) void untileKernel(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame,
                                                        uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_ranks,
-                                                       uint32_t slots)
+                                                       uint32_t rank_stride, uint32_t first_slot)
 {
     const uint32_t px = blockIdx.x * 64u + (threadIdx.x & 63u);
     const uint32_t py = blockIdx.y * 4u + (threadIdx.x >> 6);
     if (px >= width || py >= height) return;
     const uint32_t k = (py / kTile) * tiles_x + px / kTile;
     const uint32_t rank = k % n_ranks, slot = k / n_ranks;
-    const size_t src = (static_cast<size_t>(rank) * slots + slot) * (kTile * kTile) + (py % kTile) * kTile + (px % kTile);
+    // rank r's tiles start at slot r * rank_stride + first_slot (one frame: stride = slots, first = 0; frame f of a gathered
+    // batch of B frames: stride = B * slots, first = f * slots)
+    const size_t src = (static_cast<size_t>(rank) * rank_stride + first_slot + slot) * (kTile * kTile) + (py % kTile) * kTile + (px % kTile);
     frame[static_cast<size_t>(py) * width + px] = gathered[src];
 }
 
@@ -1133,11 +1135,11 @@ int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, ihipStrea
 }
 
 int launchUntile(const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height, uint32_t n_ranks,
-                 uint32_t slots, ihipStream_t* stream)
+                 uint32_t rank_stride, uint32_t first_slot, ihipStream_t* stream)
 {
     const uint32_t tiles_x = (width + kTile - 1) / kTile;
     const dim3 grid((width + 63) / 64, (height + 3) / 4), block(kBlock);
-    hipLaunchKernelGGL(untileKernel, grid, block, 0, stream, gathered, frame, width, height, tiles_x, n_ranks, slots);
+    hipLaunchKernelGGL(untileKernel, grid, block, 0, stream, gathered, frame, width, height, tiles_x, n_ranks, rank_stride, first_slot);
     return static_cast<int>(hipGetLastError());
 }
 

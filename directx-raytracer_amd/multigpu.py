@@ -28,3 +28,17 @@ def gather_frame(staging, w, h, untile, gathered=None):
     else:
         dist.all_gather_into_tensor(gathered, staging)  # also with one rank: same code path as N > 1
     return untile(gathered)
+
+
+def gather_batch(staging, w, h, n_frames, untile, gathered=None):
+    """A batch of frames rendered by one launch (crt_render_tiles_batch_device) travels in ONE all-gather: `staging` is this
+    rank's n_frames staging buffers back to back (n_frames*slots*256 elements), the gathered tensor holds
+    [rank][frame][slot] tiles, and `untile(gathered, f)` rebuilds frame f (crt_untile_batch_device).  Returns the frames."""
+    n = dist.get_world_size() if dist.is_initialized() else 1
+    if gathered is None:
+        gathered = torch.empty(n * staging.numel(), dtype=staging.dtype, device=staging.device)
+    if not dist.is_initialized():
+        gathered.copy_(staging)
+    else:
+        dist.all_gather_into_tensor(gathered, staging)
+    return [untile(gathered, f) for f in range(n_frames)]

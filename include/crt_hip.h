@@ -170,6 +170,10 @@ int crt_render_tiles_batch_device(crt_ctx* ctx, uint32_t width, uint32_t height,
 /* De-interleave a gathered buffer (n_ranks * slots * 1024 bytes, rank-major) into a row-major frame. */
 int crt_untile_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_ranks,
                       const void* d_gathered, void* d_rgba8_rowmajor);
+/* the same for frame `frame` of an all-gathered BATCH: when each rank sends its n_frames staging buffers as one contiguous
+ * message (n_frames x crt_tile_slots() tiles), d_gathered holds n_ranks x n_frames x crt_tile_slots() tiles */
+int crt_untile_batch_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_ranks, uint32_t n_frames, uint32_t frame,
+                            const void* d_gathered, void* d_rgba8);
 
 /* options. "gpu_build" 0/1: acceleration structure built on the GPU (LBVH) at the next crt_upload_scene.
  * Rendering parameters of mode 200: "spp", "max_bounces", "seed". Tuning knobs (speed only, results never

@@ -38,6 +38,13 @@ def main():
         pkg.untile_host(g.numpy().view(np.uint32), w, h, n).view(np.int32).copy()))
     got = frame.numpy().view(np.uint32).reshape(h, w)
     assert np.array_equal(got, full), "gathered frame differs on rank %d" % rank
+    # a batch of 3 frames (different images) in one all-gather: [rank][frame][slot] layout, de-interleaved per frame
+    fulls = [full, np.ascontiguousarray(full[::-1]), (full ^ np.uint32(0x00FF00FF))]
+    stag = np.concatenate([pkg.tile_host(np.where(owner == rank, f, 0).astype(np.uint32), w, h, rank, n).reshape(-1) for f in fulls])
+    frames = host.gather_batch(torch.from_numpy(stag.view(np.int32).copy()), w, h, 3, untile=lambda g, f: torch.from_numpy(
+        pkg.untile_host(g.numpy().view(np.uint32), w, h, n, n_frames=3, frame=f).view(np.int32).copy()))
+    for f in range(3):
+        assert np.array_equal(frames[f].numpy().view(np.uint32).reshape(h, w), fulls[f]), "batched gather: frame %d differs on rank %d" % (f, rank)
     share = host.rank_share(w, h, rank, n)
     assert share["tiles"] == len(range(rank, pkg.tile_count(w, h), n))
     dist.barrier()

@@ -585,6 +585,20 @@ def test_batch_launch_equals_single_frames(pkg, oracle, scenes, dragon, renderer
         renderer.render_tiles_batch_device(w, h, rank, 3, [b.data_ptr() for b in batch], cams[:3], stats=True)
         for k in range(3):
             assert torch.equal(batch[k], single[k]), (rank, k)
+        if rank == 0:
+            all_single = {0: single}
+        else:
+            all_single[rank] = single
+    # the batched all-gather layout [rank][frame][slot] + crt_untile_batch_device == the frames themselves
+    gathered = torch.cat([torch.cat(all_single[rk]) for rk in range(3)])
+    for k in range(3):
+        out = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        renderer.untile_batch_device(w, h, 3, 3, k, gathered.data_ptr(), out.data_ptr())
+        renderer.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint32), refs_for(O, cams[k], w, h)), k
+        assert np.array_equal(pkg.untile_host(gathered.cpu().numpy().view(np.uint32), w, h, 3, n_frames=3, frame=k).reshape(-1),
+                              out.cpu().numpy().view(np.uint32))
     # cameras=None: every frame uses the current camera
     renderer.set_camera(*cams[1])
     two = [torch.zeros(w * h, dtype=torch.int32, device="cuda") for _ in range(2)]
