@@ -393,7 +393,9 @@ void collapseBvh4(Bvh& bvh)
                 W.miny[i] = sl[i].box.mn[1]; W.maxy[i] = sl[i].box.mx[1];
                 W.minz[i] = sl[i].box.mn[2]; W.maxz[i] = sl[i].box.mx[2];
                 W.ref[i] = sl[i].ref; // leaf reference, or a binary index patched below when the child is emitted
-            } else {
+            } else { // unused slot: an inverted box no ray can enter, so the traversal needs no separate emptiness test
+                W.minx[i] = W.miny[i] = W.minz[i] = std::numeric_limits<float>::infinity();
+                W.maxx[i] = W.maxy[i] = W.maxz[i] = -std::numeric_limits<float>::infinity();
                 W.ref[i] = CRT_BVH_EMPTY;
             }
         }

@@ -211,7 +211,10 @@ struct Hit {
 // (15.6 instead of 29.7 steps per ray on the 1M-triangle frame).  OCT < 8: direction signs known at compile time (near
 // plane of each axis = fixed member of the (min,max) pair; fma is monotonic, so this equals the generic min/max form
 // bit for bit); OCT = 8: generic.
-constexpr int kEmptyRef = INT_MIN; // unused child slot (same value as kDone: never becomes `cur` because it never hits)
+// An unused child slot carries ref CRT_BVH_EMPTY and an inverted box (+inf, -inf).  The octant-specialised slab test takes
+// the near plane from the (min, max) pair by the direction sign, so such a box yields t_near = +inf, t_far = -inf and never
+// hits: no emptiness test there.  The generic min/max form would turn it into all of space, so it still tests the ref.
+constexpr int kEmptyRef = INT_MIN;
 
 template <int OCT>
 __device__ __forceinline__ void slab4(const float4& mnx, const float4& mxx, const float4& mny, const float4& mxy, const float4& mnz,
@@ -288,7 +291,7 @@ __device__ __forceinline__ void nodeStepClosestAt(const NodeRegs& nd, const Ray&
     uint32_t key[4];
 #pragma unroll
     for (int k = 0; k < 4; k++)
-        key[k] = (hit[k] & (rf[k] != kEmptyRef)) ? ((__float_as_uint(tn[k]) & 0x7FFFFFFCu) | static_cast<uint32_t>(k)) : 0xFFFFFFFFu;
+        key[k] = (hit[k] & (OCT < 8 || rf[k] != kEmptyRef)) ? ((__float_as_uint(tn[k]) & 0x7FFFFFFCu) | static_cast<uint32_t>(k)) : 0xFFFFFFFFu;
 #define CRT_CSWAP(a, b) { const uint32_t lo = min(key[a], key[b]), hi = max(key[a], key[b]); key[a] = lo; key[b] = hi; }
     CRT_CSWAP(0, 1) CRT_CSWAP(2, 3) CRT_CSWAP(0, 2) CRT_CSWAP(1, 3) CRT_CSWAP(1, 2)
 #undef CRT_CSWAP
@@ -313,8 +316,8 @@ __device__ __forceinline__ void nodeStepAnyAt(const NodeRegs& nd, const Ray& r, 
     float tn[4];
     bool hit[4];
     slab4<OCT>(q0, q1, q2, q3, q4, q5, r, tmin, tcull, tn, hit);
-    const bool h0 = hit[0] & (refs.x != kEmptyRef), h1 = hit[1] & (refs.y != kEmptyRef), h2 = hit[2] & (refs.z != kEmptyRef),
-               h3 = hit[3] & (refs.w != kEmptyRef);
+    const bool h0 = hit[0] & (OCT < 8 || refs.x != kEmptyRef), h1 = hit[1] & (OCT < 8 || refs.y != kEmptyRef),
+               h2 = hit[2] & (OCT < 8 || refs.z != kEmptyRef), h3 = hit[3] & (OCT < 8 || refs.w != kEmptyRef);
     if (!(h0 | h1 | h2 | h3)) {
         cur = stack.sp == 0 ? kDone : stack.pop();
     } else {

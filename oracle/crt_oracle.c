@@ -302,7 +302,9 @@ static int32_t collapse_node(collapser* C, int32_t b, uint32_t depth)
             W.miny[i] = sl[i].box.mn[1]; W.maxy[i] = sl[i].box.mx[1];
             W.minz[i] = sl[i].box.mn[2]; W.maxz[i] = sl[i].box.mx[2];
             W.ref[i] = sl[i].ref; /* binary index for now */
-        } else {
+        } else { /* unused slot: inverted box (+inf, -inf) that no ray can enter */
+            W.minx[i] = W.miny[i] = W.minz[i] = INFINITY;
+            W.maxx[i] = W.maxy[i] = W.maxz[i] = -INFINITY;
             W.ref[i] = ORACLE_EMPTY;
         }
     }
