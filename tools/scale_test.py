@@ -1,8 +1,10 @@
-import sys, importlib, statistics
-sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""Resolution scaling of the C3 view: kernel ms and Mray/s at 540p .. 8K, modes 100 and 3."""
+import sys, os, importlib, statistics
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 import __graft_entry__ as e
 import torch
-pkg=e.load_package(); scenes=importlib.import_module('directx_raytracer_amd.scenes')
+pkg=e.load_package(); scenes=importlib.import_module(e.PKG_NAME + ".scenes")
 sc=scenes.heightfield(n_lights=1); r=pkg.Renderer(0); r.upload(sc['meshes'],sc['lights'],sc['materials']); r.set_camera(sc['camera']['position'],sc['camera']['matrix'])
 for mode in (100,3):
     r.change_shading_mode(mode)
