@@ -175,7 +175,7 @@ __device__ __forceinline__ bool triTest(const Ray& r, const float4 a, const floa
 }
 
 // Per-lane traversal stack.  The first `cap` entries live in LDS (entry e of lane l at dword e*64+l: conflict free); cap
-// is chosen so that 8 wavefronts per SIMD fit the CU's 160 KB.  No ray of the test scenes ever holds more than 15
+// is chosen so that 26 wavefronts per CU fit its 160 KB (24 entries = 6 KB per wavefront).  No ray of the test scenes ever holds more than 15
 // entries while the trees are 24..26 deep, but the builder allows depth 32, so deeper entries spill to a per-lane slice
 // of a global arena that is never touched otherwise: any tree stays correct with the small LDS footprint.
 struct Stack {
@@ -376,7 +376,7 @@ __device__ __forceinline__ void nodeStepAny(const float4* __restrict__ nodes, co
 // and counters do not depend on what the other lanes do), but WHEN a lane's next step runs is decided per wavefront:
 // node steps are issued while at least `innerMin` lanes still stand on inner nodes (or nobody waits at a leaf); then the
 // lanes waiting at leaves intersect their triangles.  innerMin = 1 is the classic while-while loop (leaves wait until
-// every lane has one: 47 % of the lanes active on the 1M-triangle frame); 24 measured best (0.67 vs 1.10 ms).
+// every lane has one: 47 % of the lanes active on the 1M-triangle frame); 32 measured best (first measurement: 0.67 vs 1.10 ms; re-swept after every structural change).
 template <bool COUNT, int BLOCK, int OCT>
 __device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                              uint32_t n_nodes, const Ray& r, float tmin, float tmax, Stack& stack, int innerMin,
