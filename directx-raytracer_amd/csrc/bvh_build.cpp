@@ -5,6 +5,7 @@
 // three axes in a single sweep; large ranges fork their left half as an OpenMP task (ranges are disjoint, so
 // the result does not depend on scheduling); nodes are allocated from a shared pool in arbitrary order and
 // renumbered to DFS pre-order at the end.
+#include "mem_util.h"
 #include "bvh_build.h"
 
 #include <atomic>
@@ -137,7 +138,7 @@ struct Builder {
                 if (binOf(p, bestAxis, lo, sc) < bestPlane) order[first + nl++] = p;
                 else scratch[first + nr++] = p;
             }
-            std::memcpy(order + first + nl, scratch + first, sizeof(uint32_t) * nr);
+            crt::copyBytes(order + first + nl, scratch + first, sizeof(uint32_t) * nr);
             nLeft = nl;
             const uint64_t cap = static_cast<uint64_t>(kLeafMax) << (kMaxDepth - depth - 1);
             if (static_cast<uint64_t>(nl > nr ? nl : nr) > cap) nLeft = 0;
@@ -214,9 +215,9 @@ void flattenMeshes(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<c
             std::memset(&S, 0, sizeof(S));
             S.material = static_cast<uint32_t>(M.material_index);
             if (M.normals) {
-                std::memcpy(S.n0, M.normals + 3 * static_cast<size_t>(i0), 12);
-                std::memcpy(S.n1, M.normals + 3 * static_cast<size_t>(i1), 12);
-                std::memcpy(S.n2, M.normals + 3 * static_cast<size_t>(i2), 12);
+                crt::copyBytes(S.n0, M.normals + 3 * static_cast<size_t>(i0), 12);
+                crt::copyBytes(S.n1, M.normals + 3 * static_cast<size_t>(i1), 12);
+                crt::copyBytes(S.n2, M.normals + 3 * static_cast<size_t>(i2), 12);
             }
         }
     }
@@ -238,9 +239,9 @@ void flattenUvs(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<crt_
         const crt_mesh_view& M = meshes[m];
         for (uint32_t t = 0; t < M.n_triangles; t++, g++) {
             if (!M.uvs) continue;
-            std::memcpy(inUv[g].uv0, M.uvs + 3 * static_cast<size_t>(M.idx[3 * t]), 8);
-            std::memcpy(inUv[g].uv1, M.uvs + 3 * static_cast<size_t>(M.idx[3 * t + 1]), 8);
-            std::memcpy(inUv[g].uv2, M.uvs + 3 * static_cast<size_t>(M.idx[3 * t + 2]), 8);
+            crt::copyBytes(inUv[g].uv0, M.uvs + 3 * static_cast<size_t>(M.idx[3 * t]), 8);
+            crt::copyBytes(inUv[g].uv1, M.uvs + 3 * static_cast<size_t>(M.idx[3 * t + 1]), 8);
+            crt::copyBytes(inUv[g].uv2, M.uvs + 3 * static_cast<size_t>(M.idx[3 * t + 2]), 8);
         }
     }
 }
@@ -273,9 +274,9 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
     std::vector<Box> primBox(n);
     std::vector<float> cent(3 * static_cast<size_t>(n));
     for (uint32_t i = 0; i < n; i++) {
-        std::memcpy(primBox[i].mn, &boxCent[9 * static_cast<size_t>(i)], 12);
-        std::memcpy(primBox[i].mx, &boxCent[9 * static_cast<size_t>(i) + 3], 12);
-        std::memcpy(&cent[3 * static_cast<size_t>(i)], &boxCent[9 * static_cast<size_t>(i) + 6], 12);
+        crt::copyBytes(primBox[i].mn, &boxCent[9 * static_cast<size_t>(i)], 12);
+        crt::copyBytes(primBox[i].mx, &boxCent[9 * static_cast<size_t>(i) + 3], 12);
+        crt::copyBytes(&cent[3 * static_cast<size_t>(i)], &boxCent[9 * static_cast<size_t>(i) + 6], 12);
     }
 
     std::vector<uint32_t> order(n), scratch(n);

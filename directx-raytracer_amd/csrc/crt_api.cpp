@@ -1,6 +1,7 @@
 // C ABI of libcrt_hip.so (include/crt_hip.h): renderer context over the HIP runtime + scene-layer accessors.
 // Each entry point cites the reference member it replaces in the header.  No CPU fallback exists here: every
 // render path ends in launchRender() (render_kernels.hip).
+#include "mem_util.h"
 #include "../../include/crt_hip.h"
 
 #include "bvh_build.h"
@@ -158,9 +159,9 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.n_tris = static_cast<uint32_t>(c->bvh.tris.size());
     p.n_lights = c->nLights;
     p.n_mats = c->nMats;
-    std::memcpy(p.pos, c->pos, sizeof(p.pos));
-    std::memcpy(p.rot, c->rot, sizeof(p.rot));
-    std::memcpy(p.miss, c->miss, sizeof(p.miss));
+    crt::copyBytes(p.pos, c->pos, sizeof(p.pos));
+    crt::copyBytes(p.rot, c->rot, sizeof(p.rot));
+    crt::copyBytes(p.miss, c->miss, sizeof(p.miss));
     p.mode = c->mode;
     p.spp = c->pathSpp;
     p.max_bounces = c->pathBounces;
@@ -418,9 +419,9 @@ int crt_bvh_build_host(const crt_mesh_view* meshes, uint32_t n_meshes, crt_bvh_n
         *tris = static_cast<crt_bvh_tri*>(std::malloc(sizeof(crt_bvh_tri) * (b.tris.size() + 1)));
         if (shade) *shade = static_cast<crt_bvh_shade*>(std::malloc(sizeof(crt_bvh_shade) * (b.tris.size() + 1)));
         if (!*nodes || !*tris || (shade && !*shade)) return fail(nullptr, CRT_ENOMEM, "out of host memory");
-        std::memcpy(*nodes, b.nodes.data(), sizeof(crt_bvh_node) * b.nodes.size());
-        std::memcpy(*tris, b.tris.data(), sizeof(crt_bvh_tri) * b.tris.size());
-        if (shade) std::memcpy(*shade, b.shade.data(), sizeof(crt_bvh_shade) * b.shade.size());
+        crt::copyBytes(*nodes, b.nodes.data(), sizeof(crt_bvh_node) * b.nodes.size());
+        crt::copyBytes(*tris, b.tris.data(), sizeof(crt_bvh_tri) * b.tris.size());
+        if (shade) crt::copyBytes(*shade, b.shade.data(), sizeof(crt_bvh_shade) * b.shade.size());
     } catch (const std::exception& ex) {
         return fail(nullptr, CRT_EINVAL, "BVH build failed: %s", ex.what());
     }
@@ -490,8 +491,8 @@ int crt_set_textures(crt_ctx* c, const crt_texture* textures, uint32_t n)
         if (t.type > 3u) return fail(c, CRT_EINVAL, "texture %u: unknown type %u", i, t.type);
         crt::TextureRec& r = recs[i];
         r.type = t.type;
-        std::memcpy(r.a, t.color_a, 12);
-        std::memcpy(r.b, t.color_b, 12);
+        crt::copyBytes(r.a, t.color_a, 12);
+        crt::copyBytes(r.b, t.color_b, 12);
         r.scalar = t.scalar;
         r.texel_offset = r.width = r.height = r.channels = 0;
         if (t.type == 3u) {
@@ -521,7 +522,7 @@ int crt_bvh_export_uv(const crt_ctx* c, crt_bvh_uv* uvs, int* has_uvs)
 {
     if (!c || !c->haveScene) return CRT_ESTATE;
     if (has_uvs) *has_uvs = c->bvh.uvs.empty() ? 0 : 1;
-    if (uvs && !c->bvh.uvs.empty()) std::memcpy(uvs, c->bvh.uvs.data(), sizeof(crt_bvh_uv) * c->bvh.uvs.size());
+    if (uvs && !c->bvh.uvs.empty()) crt::copyBytes(uvs, c->bvh.uvs.data(), sizeof(crt_bvh_uv) * c->bvh.uvs.size());
     return CRT_OK;
 }
 
@@ -530,8 +531,8 @@ int crt_set_camera(crt_ctx* c, const float pos[3], const float rot[9])
     if (!c) return CRT_EINVAL;
     if (!pos || !rot) return fail(c, CRT_EINVAL, "crt_set_camera: NULL argument");
     if (std::memcmp(c->pos, pos, sizeof(c->pos)) != 0 || std::memcmp(c->rot, rot, sizeof(c->rot)) != 0) c->viewSerial++;
-    std::memcpy(c->pos, pos, sizeof(c->pos));
-    std::memcpy(c->rot, rot, sizeof(c->rot));
+    crt::copyBytes(c->pos, pos, sizeof(c->pos));
+    crt::copyBytes(c->rot, rot, sizeof(c->rot));
     return CRT_OK;
 }
 
@@ -547,7 +548,7 @@ int crt_set_miss_color(crt_ctx* c, const float rgb[3])
 {
     if (!c) return CRT_EINVAL;
     if (!rgb) return fail(c, CRT_EINVAL, "crt_set_miss_color: NULL argument");
-    std::memcpy(c->miss, rgb, sizeof(c->miss));
+    crt::copyBytes(c->miss, rgb, sizeof(c->miss));
     return CRT_OK;
 }
 
@@ -743,13 +744,13 @@ int runBatch(crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_t n_ranks
     p.n_batch = n_frames;
     p.rgba8 = static_cast<uint32_t*>(d_out[0]);
     if (cameras) {
-        std::memcpy(p.pos, cameras, sizeof(p.pos));
-        std::memcpy(p.rot, cameras + 3, sizeof(p.rot));
+        crt::copyBytes(p.pos, cameras, sizeof(p.pos));
+        crt::copyBytes(p.rot, cameras + 3, sizeof(p.rot));
     }
     for (uint32_t f = 1; f < n_frames; f++) {
         const float* cam = cameras ? cameras + 12 * f : nullptr;
-        std::memcpy(p.batch_pos[f - 1], cam ? cam : c->pos, sizeof(p.pos));
-        std::memcpy(p.batch_rot[f - 1], cam ? cam + 3 : c->rot, sizeof(p.rot));
+        crt::copyBytes(p.batch_pos[f - 1], cam ? cam : c->pos, sizeof(p.pos));
+        crt::copyBytes(p.batch_rot[f - 1], cam ? cam + 3 : c->rot, sizeof(p.rot));
         p.batch_rgba8[f - 1] = static_cast<uint32_t*>(d_out[f]);
     }
     rc = runRender(c, p, stats);
@@ -817,7 +818,7 @@ int crt_bvh_info4(const crt_ctx* c, uint32_t* n_nodes4, uint32_t* depth4)
 int crt_bvh_export4(const crt_ctx* c, crt_bvh_node4* nodes4)
 {
     if (!c || !c->haveScene) return CRT_ESTATE;
-    if (nodes4) std::memcpy(nodes4, c->bvh.nodes4.data(), sizeof(crt_bvh_node4) * c->bvh.nodes4.size());
+    if (nodes4) crt::copyBytes(nodes4, c->bvh.nodes4.data(), sizeof(crt_bvh_node4) * c->bvh.nodes4.size());
     return CRT_OK;
 }
 
@@ -831,7 +832,7 @@ int crt_bvh_build_host4(const crt_mesh_view* meshes, uint32_t n_meshes, crt_bvh_
         if (depth4) *depth4 = b.depth4;
         *nodes4 = static_cast<crt_bvh_node4*>(std::malloc(sizeof(crt_bvh_node4) * (b.nodes4.size() + 1)));
         if (!*nodes4) return fail(nullptr, CRT_ENOMEM, "out of host memory");
-        std::memcpy(*nodes4, b.nodes4.data(), sizeof(crt_bvh_node4) * b.nodes4.size());
+        crt::copyBytes(*nodes4, b.nodes4.data(), sizeof(crt_bvh_node4) * b.nodes4.size());
     } catch (const std::exception& ex) {
         return fail(nullptr, CRT_EINVAL, "BVH build failed: %s", ex.what());
     }
@@ -841,9 +842,9 @@ int crt_bvh_build_host4(const crt_mesh_view* meshes, uint32_t n_meshes, crt_bvh_
 int crt_bvh_export(const crt_ctx* c, crt_bvh_node* nodes, crt_bvh_tri* tris, crt_bvh_shade* shade)
 {
     if (!c || !c->haveScene) return CRT_ESTATE;
-    if (nodes) std::memcpy(nodes, c->bvh.nodes.data(), sizeof(crt_bvh_node) * c->bvh.nodes.size());
-    if (tris) std::memcpy(tris, c->bvh.tris.data(), sizeof(crt_bvh_tri) * c->bvh.tris.size());
-    if (shade) std::memcpy(shade, c->bvh.shade.data(), sizeof(crt_bvh_shade) * c->bvh.shade.size());
+    if (nodes) crt::copyBytes(nodes, c->bvh.nodes.data(), sizeof(crt_bvh_node) * c->bvh.nodes.size());
+    if (tris) crt::copyBytes(tris, c->bvh.tris.data(), sizeof(crt_bvh_tri) * c->bvh.tris.size());
+    if (shade) crt::copyBytes(shade, c->bvh.shade.data(), sizeof(crt_bvh_shade) * c->bvh.shade.size());
     return CRT_OK;
 }
 
@@ -942,7 +943,7 @@ int crt_scene_light(const crt_scene* s, uint32_t i, crt_light* out)
 {
     if (!s || !out || i >= s->scene.getLights().size()) return CRT_EINVAL;
     const crt::Light& l = s->scene.getLights()[i];
-    std::memcpy(out->pos, l.getPosition().data(), 12);
+    crt::copyBytes(out->pos, l.getPosition().data(), 12);
     out->intensity = l.getIntensity();
     return CRT_OK;
 }
@@ -953,7 +954,7 @@ int crt_scene_material(const crt_scene* s, uint32_t i, crt_material* out)
 {
     if (!s || !out || i >= s->scene.getMaterials().size()) return CRT_EINVAL;
     const crt::Material& m = s->scene.getMaterials()[i];
-    std::memcpy(out->albedo, m.getAlbedo().data(), 12);
+    crt::copyBytes(out->albedo, m.getAlbedo().data(), 12);
     out->type = static_cast<uint32_t>(m.getType());
     out->smooth = m.isSmoothShading() ? 1u : 0u;
     out->ior = m.getIor();
@@ -967,7 +968,7 @@ int crt_scene_texture_color(const crt_scene* s, uint32_t i, float u, float v, fl
 {
     if (!s || !out_rgb || i >= s->scene.getTextures().size()) return CRT_EINVAL;
     const crt::Vector c = s->scene.getTextures()[i].getColor(u, v);
-    std::memcpy(out_rgb, c.data(), 12);
+    crt::copyBytes(out_rgb, c.data(), 12);
     return CRT_OK;
 }
 
@@ -1017,15 +1018,15 @@ int crt_scene_settings(const crt_scene* s, uint32_t* width, uint32_t* height, fl
     const crt::Settings& st = s->scene.getSettings();
     if (width) *width = static_cast<uint32_t>(st.imageWidth);
     if (height) *height = static_cast<uint32_t>(st.imageHeight);
-    if (background_rgb) std::memcpy(background_rgb, st.backgroundColor.data(), 12);
+    if (background_rgb) crt::copyBytes(background_rgb, st.backgroundColor.data(), 12);
     return CRT_OK;
 }
 
 int crt_scene_camera_get(const crt_scene* s, float pos[3], float rot[9])
 {
     if (!s) return CRT_EINVAL;
-    if (pos) std::memcpy(pos, s->scene.getCamera().getPosition().data(), 12);
-    if (rot) std::memcpy(rot, s->scene.getCamera().getRotationMatrix().data(), 36);
+    if (pos) crt::copyBytes(pos, s->scene.getCamera().getPosition().data(), 12);
+    if (rot) crt::copyBytes(rot, s->scene.getCamera().getRotationMatrix().data(), 36);
     return CRT_OK;
 }
 
@@ -1077,8 +1078,8 @@ int crt_upload_scene_from(crt_ctx* c, const crt_scene* s)
     for (const crt::TextureDesc& t : s->scene.getTextures()) {
         crt_texture x{};
         x.type = t.typeCode();
-        std::memcpy(x.color_a, t.colorA.data(), 12);
-        std::memcpy(x.color_b, t.colorB.data(), 12);
+        crt::copyBytes(x.color_a, t.colorA.data(), 12);
+        crt::copyBytes(x.color_b, t.colorB.data(), 12);
         x.scalar = t.scalar;
         x.pixels = t.pixels.empty() ? nullptr : t.pixels.data();
         x.width = static_cast<uint32_t>(t.width);

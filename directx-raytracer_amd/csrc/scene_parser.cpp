@@ -2,6 +2,7 @@
 // (top-level keys settings / camera / objects / lights / materials / textures, parse order of :414-419);
 // where the reference reads an absent key through MemberEnd() or leaves a field uninitialised
 // (:87,:123-130,:196,:347-391 -- SURVEY.md section 5 "Parser hazards") this reader uses a default instead.
+#include "mem_util.h"
 #include "json_min.h"
 #include "scene.h"
 
@@ -257,14 +258,14 @@ struct Reader {
     {
         if (static_cast<size_t>(end - p) < sizeof(T)) throw std::runtime_error("crtbin: truncated file");
         T v;
-        std::memcpy(&v, p, sizeof(T));
+        crt::copyBytes(&v, p, sizeof(T));
         p += sizeof(T);
         return v;
     }
     void bytes(void* dst, size_t n)
     {
         if (static_cast<size_t>(end - p) < n) throw std::runtime_error("crtbin: truncated file");
-        std::memcpy(dst, p, n);
+        crt::copyBytes(dst, p, n);
         p += n;
     }
     std::string str()
