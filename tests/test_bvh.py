@@ -171,3 +171,31 @@ def test_nan_vertices_do_not_break_the_builders(pkg, oracle):
         O = oracle.OracleScene([{"vertices": w, "triangles": t}])
         assert nodes.tobytes() == O.nodes().tobytes() and tris.tobytes() == O.tris().tobytes()
         assert sorted(tris["gid"].tolist()) == list(range(100))
+
+
+def test_random_meshes_both_builders_agree(pkg, oracle):
+    """Property test: for arbitrary small meshes (coincident vertices, zero-area and repeated triangles, huge / tiny
+    coordinates, several meshes) the product's builder and the oracle's independent implementation emit the same bytes
+    (binary tree, wide tree, leaf-ordered records) and the structural invariants hold."""
+    from hypothesis import given, settings, strategies as st
+
+    coord = st.one_of(st.floats(-20, 20, width=32), st.sampled_from([0.0, 1.0, -1.0, 1e-20, 1e20, -1e20, 3.4e38]),
+                      st.integers(-3, 3).map(float))
+    mesh = st.integers(1, 40).flatmap(lambda nv: st.tuples(
+        st.lists(st.tuples(coord, coord, coord), min_size=nv, max_size=nv),
+        st.lists(st.tuples(*[st.integers(0, nv - 1)] * 3), min_size=0, max_size=60)))
+
+    @settings(max_examples=120, deadline=None)
+    @given(st.lists(mesh, min_size=1, max_size=3))
+    def run(ms):
+        meshes = [{"vertices": np.float32(v).reshape(-1, 3), "triangles": np.uint32(t).reshape(-1, 3), "material_index": i}
+                  for i, (v, t) in enumerate(ms)]
+        n_tris = sum(len(m["triangles"]) for m in meshes)
+        nodes, tris, shade, md = pkg.build_bvh_host(meshes)
+        O = oracle.OracleScene(meshes)
+        assert nodes.tobytes() == O.nodes().tobytes() and tris.tobytes() == O.tris().tobytes() and shade.tobytes() == O.shade().tobytes()
+        nodes4, depth4 = pkg.build_bvh4_host(meshes)
+        assert nodes4.tobytes() == O.nodes4().tobytes() and depth4 == O.depth4 and md == O.max_depth
+        assert len(tris) == n_tris and sorted(tris["gid"].tolist()) == list(range(n_tris)) and md <= 32
+
+    run()
