@@ -614,3 +614,55 @@ def test_batch_launch_equals_single_frames(pkg, oracle, scenes, dragon, renderer
 
 def refs_for(O, cam, w, h):
     return O.render(cam[0], cam[1], 100, w, h)["rgba8"].reshape(-1, 4).copy().view(np.uint32).ravel()
+
+
+def test_random_scenes_property(pkg, oracle, scenes, renderer):
+    """Property test on the device: random small scenes on an integer lattice (coplanar and duplicated triangles -> equal-t
+    ties, zero-area triangles, boxes of zero thickness), cameras on lattice points looking along axes or arbitrary angles
+    (direction components exactly 0 -> the 1e-20 clamp, rays inside box faces), all of it against the oracle: hit ids,
+    t, RGBA8, float colour and the fetch counters, for primary rays, shadow rays and path tracing."""
+    from hypothesis import given, settings, strategies as st, HealthCheck
+
+    lattice = st.integers(-4, 4).map(float)
+    coord = st.one_of(lattice, lattice, st.floats(-4, 4, width=32))
+    tri = st.tuples(*[st.tuples(coord, coord, coord)] * 3)
+    cam_pos = st.tuples(st.integers(-6, 6).map(float), st.integers(-6, 6).map(float), st.integers(3, 9).map(float))
+    angles = st.one_of(st.sampled_from([(0.0, 0.0), (90.0, 0.0), (180.0, 0.0), (0.0, 45.0), (45.0, 0.0)]),
+                       st.tuples(st.floats(-180, 180, width=32), st.floats(-80, 80, width=32)))
+    w, h = 33, 17
+
+    @settings(max_examples=int(os.environ.get("CRT_PROPERTY_EXAMPLES", "60")), deadline=None, suppress_health_check=[HealthCheck.function_scoped_fixture])
+    @given(st.lists(tri, min_size=1, max_size=24), st.integers(1, 3), cam_pos, angles, st.integers(0, 2 ** 31 - 1))
+    def run(tris, n_meshes, pos, ang, seed):
+        v = np.float32(tris).reshape(-1, 3)
+        t = np.arange(len(v), dtype=np.uint32).reshape(-1, 3)
+        cut = [len(t) * k // n_meshes for k in range(n_meshes + 1)]
+        meshes = [{"vertices": v, "triangles": t[cut[k]:cut[k + 1]], "material_index": k % 3} for k in range(n_meshes) if cut[k + 1] > cut[k]]
+        mats = [{"albedo": (0.8, 0.7, 0.6), "type": 1}, {"albedo": (0.9, 0.9, 0.9), "type": 2}, {"albedo": (1.0, 1.0, 1.0), "type": 3, "ior": 1.5}]
+        lights = [((2.0, 5.0, 3.0), 300.0), ((-3.0, -2.0, 6.0), 150.0)]
+        rot = scenes.camera_matrix(yaw_deg=float(ang[0]), pitch_deg=float(ang[1]))
+        renderer.upload(meshes, lights, mats)
+        renderer.set_camera(pos, rot)
+        O = oracle.OracleScene(meshes, lights, mats)
+        for mode in (3, 100, pkg.MODE_PATH):
+            renderer.change_shading_mode(mode)
+            if mode == pkg.MODE_PATH:
+                renderer.set_path_params(2, 2, seed)
+                oracle.set_path_params(2, 2, seed)
+            for counting in (False, True):
+                renderer.set_counting(counting)
+                got = renderer.render_frame(w, h)
+                ref = O.render(pos, rot, mode, w, h)
+                for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
+                    np.testing.assert_array_equal(got[k], ref[k], err_msg="mode %d %s counting=%s" % (mode, k, counting))
+                assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True), "mode %d rgb" % mode
+                if counting:
+                    st_, rs = got["stats"], ref["stats"]
+                    assert (st_["rays_shadow"], st_["nodes_visited"], st_["tris_tested"]) == (rs["rays_shadow"], rs["nodes_visited"], rs["tris_tested"])
+
+    try:
+        run()
+    finally:
+        renderer.set_counting(False)
+        renderer.set_path_params(4, 3, 1234)
+        oracle.set_path_params(4, 3, 1234)
