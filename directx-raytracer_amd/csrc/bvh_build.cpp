@@ -189,12 +189,19 @@ void flattenMeshes(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<c
     inTri.resize(n);
     inShade.resize(n);
     boxCent.resize(9 * static_cast<size_t>(n));
-    uint32_t g = 0;
+    uint32_t g0 = 0;
+    bool bad = false; // an exception must not leave the parallel region: remember, finish, throw afterwards
     for (uint32_t m = 0; m < n_meshes; m++) {
         const crt_mesh_view& M = meshes[m];
-        for (uint32_t t = 0; t < M.n_triangles; t++, g++) {
+        const long long nt = static_cast<long long>(M.n_triangles);
+#pragma omp parallel for schedule(static) if (nt > 65536) reduction(|| : bad)
+        for (long long tt = 0; tt < nt; tt++) {
+            const uint32_t t = static_cast<uint32_t>(tt), g = g0 + t;
             const uint32_t i0 = M.idx[3 * t], i1 = M.idx[3 * t + 1], i2 = M.idx[3 * t + 2];
-            if (i0 >= M.n_vertices || i1 >= M.n_vertices || i2 >= M.n_vertices) throw std::runtime_error("triangle index out of range");
+            if (i0 >= M.n_vertices || i1 >= M.n_vertices || i2 >= M.n_vertices) {
+                bad = true;
+                continue;
+            }
             const float* A = M.xyz + 3 * static_cast<size_t>(i0);
             const float* B = M.xyz + 3 * static_cast<size_t>(i1);
             const float* C = M.xyz + 3 * static_cast<size_t>(i2);
@@ -220,6 +227,8 @@ void flattenMeshes(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<c
                 crt::copyBytes(S.n2, M.normals + 3 * static_cast<size_t>(i2), 12);
             }
         }
+        if (bad) throw std::runtime_error("triangle index out of range");
+        g0 += M.n_triangles;
     }
 }
 

@@ -227,6 +227,15 @@ struct DevBuf {
 
 void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipStream_t* stream, double* device_ms)
 {
+    const bool timing = std::getenv("CRT_BUILD_TIMING") != nullptr;
+    auto tnow = [] { return std::chrono::steady_clock::now(); };
+    auto tlast = tnow();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto t = tnow();
+        std::fprintf(stderr, "[build] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tlast).count());
+        tlast = t;
+    };
     std::vector<crt_bvh_tri> inTri;
     std::vector<crt_bvh_shade> inShade;
     std::vector<float> pboxCent; // per triangle: 6 floats box + 3 floats centroid (9 floats)
@@ -239,6 +248,7 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
     flattenUvs(meshes, n_meshes, inUv);
     if (device_ms) *device_ms = 0.0;
     if (n == 0) return;
+    lap("host flatten");
 
     // split the interleaved host array into the two device arrays the kernels read
     std::vector<Box6> hBox(n);
@@ -313,6 +323,8 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
     GPU_TRY(hipMemcpyAsync(dInTri.p, inTri.data(), sizeof(crt_bvh_tri) * n, hipMemcpyHostToDevice, stream));
     GPU_TRY(hipMemcpyAsync(dInShade.p, inShade.data(), sizeof(crt_bvh_shade) * n, hipMemcpyHostToDevice, stream));
 
+    if (timing) { GPU_TRY(hipStreamSynchronize(stream)); }
+    lap("alloc + H2D inputs");
     hipEvent_t e0, e1;
     GPU_TRY(hipEventCreate(&e0));
     GPU_TRY(hipEventCreate(&e1));
@@ -340,6 +352,8 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
                        dTris.as<crt_bvh_tri>(), dShade.as<crt_bvh_shade>());
     GPU_TRY(hipGetLastError());
     GPU_TRY(hipEventRecord(e1, stream));
+    if (timing) { GPU_TRY(hipStreamSynchronize(stream)); }
+    lap("device build");
     out.nodes.resize(nKept);
     GPU_TRY(hipMemcpyAsync(out.nodes.data(), dNodes.p, sizeof(crt_bvh_node) * nKept, hipMemcpyDeviceToHost, stream));
     GPU_TRY(hipMemcpyAsync(out.tris.data(), dTris.p, sizeof(crt_bvh_tri) * n, hipMemcpyDeviceToHost, stream));
@@ -350,6 +364,7 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (device_ms) *device_ms = ms;
+    lap("D2H nodes/tris/shade");
 
     // depth of the binary tree (levels of nodes + the leaf level), then the shared host collapse to the wide tree
     {
@@ -365,8 +380,11 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
         }
         out.maxDepth = deepest;
     }
+    lap("host depth walk");
     collapseBvh4(out);
+    lap("host collapse");
     reorderUvs(inUv, out);
+    lap("uv reorder");
 }
 
 } // namespace crt
