@@ -705,3 +705,98 @@ def test_gpu_bvh_build_property(pkg, oracle, scenes):
         run()
     finally:
         r.close()
+
+
+def test_runtime_state_machine_stress(pkg, oracle, scenes, dragon, renderer):
+    """Randomised sequences over the runtime layer -- stream switches (own / torch streams), frame-size changes, camera and
+    mode changes, adaptive_order policies, single frames, batches and tile shares issued back to back without host
+    synchronisation -- every frame into its own sentinel-filled buffer, all checked at the end against references
+    rendered one at a time.  Exercises the scratch ring, the cost/order buffers and their events, order reuse for an
+    unchanged view, and the spill arenas under reordering."""
+    import random
+    import torch
+    sc = _with_normals(scenes, dragon)
+    base = sc["camera"]
+    renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+    rng = random.Random(20260104)
+    sizes = [(160, 90), (97, 61), (256, 144)]
+    cams = [(np.float32(base["position"]) + np.float32([0.9 * k, 0.2 * k, -0.5 * k]), scenes.camera_matrix(yaw_deg=5.0 * k, pitch_deg=-3.0 * k)) for k in range(3)]
+    modes = [3, 100]
+    # references: one synchronous frame per (size, camera, mode), checked against the oracle
+    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    refs = {}
+    renderer.reset_stream()
+    for si, (w, h) in enumerate(sizes):
+        for ci, (p, r) in enumerate(cams):
+            for m in modes:
+                renderer.set_camera(p, r)
+                renderer.change_shading_mode(m)
+                got = renderer.render_frame(w, h, want=())["rgba8"].reshape(-1, 4).copy().view(np.uint32).ravel()
+                if si == 0:
+                    np.testing.assert_array_equal(got, O.render(p, r, m, w, h)["rgba8"].reshape(-1, 4).copy().view(np.uint32).ravel())
+                refs[(si, ci, m)] = got
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    pending = []  # (buffer, key, kind)
+    try:
+        for rounds in range(max(6, int(os.environ.get("CRT_PROPERTY_EXAMPLES", "60")) // 10)):
+            si, ci, m = 0, 0, 100
+            renderer.set_camera(*cams[ci]); renderer.change_shading_mode(m)
+            # plan the round first and allocate every output up front, so that the issue loop below never synchronises
+            plan = []
+            for step in range(48):
+                op = rng.random()
+                pre = None
+                if op < 0.15:
+                    ci = rng.randrange(3); pre = ("cam", ci)
+                elif op < 0.25:
+                    m = rng.choice(modes); pre = ("mode", m)
+                elif op < 0.35:
+                    si = rng.randrange(3)
+                elif op < 0.45:
+                    pre = ("order", rng.choice([0, 1, 2]))
+                elif op < 0.6:
+                    pre = ("stream", rng.randrange(4))
+                w, h = sizes[si]
+                kind = rng.random()
+                if kind < 0.6:
+                    bufs = [torch.full((w * h,), 0x7E57AB1E, dtype=torch.int32, device="cuda")]
+                    what = ("frame", None)
+                elif kind < 0.8:
+                    bufs = [torch.full((w * h,), 0x7E57AB1E, dtype=torch.int32, device="cuda") for _ in range(rng.randrange(1, 5))]
+                    what = ("batch", None)
+                else:
+                    n = rng.choice([2, 3, 8]); rank = rng.randrange(n)
+                    bufs = [torch.zeros(pkg.tile_slots(w, h, n) * 256, dtype=torch.int32, device="cuda")]
+                    what = ("tiles", (rank, n))
+                plan.append((pre, (w, h), what, bufs, (si, ci, m)))
+            torch.cuda.synchronize()
+            for pre, (w, h), (kind, extra), bufs, key in plan:
+                if pre:
+                    if pre[0] == "cam": renderer.set_camera(*cams[pre[1]])
+                    elif pre[0] == "mode": renderer.change_shading_mode(pre[1])
+                    elif pre[0] == "order": renderer.set_option("adaptive_order", pre[1])
+                    elif pre[1] == 3: renderer.reset_stream()
+                    else: renderer.set_stream(streams[pre[1]].cuda_stream)
+                if kind == "frame":
+                    renderer.render_frame_device(w, h, bufs[0].data_ptr())
+                elif kind == "batch":
+                    renderer.render_frames_batch_device(w, h, [b.data_ptr() for b in bufs])
+                else:
+                    renderer.render_tiles_device(w, h, extra[0], extra[1], bufs[0].data_ptr())
+                pending += [(b, key, "tiles" if kind == "tiles" else "frame", extra) for b in bufs]
+            torch.cuda.synchronize()
+            renderer.synchronize()
+            for b, key, kind, extra in pending:
+                w, h = sizes[key[0]]
+                if kind == "frame":
+                    assert np.array_equal(b.cpu().numpy().view(np.uint32), refs[key]), (rounds, key)
+                else:
+                    rank, n = extra
+                    exp = pkg.tile_host(refs[key].reshape(h, w), w, h, rank, n).reshape(-1)
+                    assert np.array_equal(b.cpu().numpy().view(np.uint32), exp), (rounds, key, extra)
+            pending.clear()
+    finally:
+        torch.cuda.synchronize()
+        renderer.set_option("adaptive_order", 2)
+        renderer.reset_stream()
+        renderer.set_camera(base["position"], base["matrix"])
