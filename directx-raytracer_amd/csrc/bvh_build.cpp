@@ -11,6 +11,12 @@
 #include <atomic>
 #include <cmath>
 #include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <omp.h>
+#include <sched.h>
+#include <algorithm>
 #include <limits>
 #include <stdexcept>
 
@@ -37,6 +43,9 @@ struct Box {
     }
 };
 
+// ranges at least this long run their sweeps in parallel chunks (Builder::build)
+constexpr uint32_t kParallelSweep = 131072;
+
 struct TempNode {
     Box lb, rb;
     int32_t left, right; // >= 0: pool index, < 0: final leaf reference
@@ -61,16 +70,39 @@ struct Builder {
 
     int32_t build(uint32_t first, uint32_t count, uint32_t depth, Box& bounds)
     {
+        // Large ranges (the top levels of the tree, which are otherwise one thread's work while the others wait) run their
+        // three sweeps chunk-parallel on the task team.  Everything merged across chunks is a min, a max, a count or a
+        // stable concatenation, so the result is the sequential one bit for bit.
+        const uint32_t nChunks = count >= kParallelSweep ? std::min<uint32_t>(64u, count / (kParallelSweep / 4u)) : 1u;
+        const uint32_t chunkLen = (count + nChunks - 1u) / nChunks;
         Box cb;
         bounds.clear();
         cb.clear();
-        for (uint32_t i = first; i < first + count; i++) {
-            const uint32_t p = order[i];
-            bounds.grow(primBox[p]);
-            for (int a = 0; a < 3; a++) {
-                const float c = cent[3 * p + a];
-                cb.mn[a] = fmin_sel(cb.mn[a], c);
-                cb.mx[a] = fmax_sel(cb.mx[a], c);
+        auto sweepBounds = [&](uint32_t b, uint32_t e, Box& bb, Box& cc) {
+            for (uint32_t i = b; i < e; i++) {
+                const uint32_t p = order[i];
+                bb.grow(primBox[p]);
+                for (int a = 0; a < 3; a++) {
+                    const float c = cent[3 * p + a];
+                    cc.mn[a] = fmin_sel(cc.mn[a], c);
+                    cc.mx[a] = fmax_sel(cc.mx[a], c);
+                }
+            }
+        };
+        if (nChunks == 1u) {
+            sweepBounds(first, first + count, bounds, cb);
+        } else {
+            std::vector<Box> pb(nChunks), pc(nChunks);
+#pragma omp taskloop grainsize(1) shared(pb, pc)
+            for (uint32_t c = 0; c < nChunks; c++) {
+                pb[c].clear();
+                pc[c].clear();
+                const uint32_t b = first + c * chunkLen, e = std::min(first + count, b + chunkLen);
+                sweepBounds(b, e, pb[c], pc[c]);
+            }
+            for (uint32_t c = 0; c < nChunks; c++) {
+                bounds.grow(pb[c]);
+                cb.grow(pc[c]);
             }
         }
         uint32_t seen = deepest.load(std::memory_order_relaxed);
@@ -88,14 +120,35 @@ struct Builder {
             scale[a] = live[a] ? static_cast<float>(kBins) / ext : 0.0f;
             for (int b = 0; b < kBins; b++) { binBox[a][b].clear(); binCnt[a][b] = 0; }
         }
-        for (uint32_t i = first; i < first + count; i++) {
-            const uint32_t p = order[i];
-            for (int a = 0; a < 3; a++) {
-                if (!live[a]) continue;
-                const int b = binOf(p, a, cb.mn[a], scale[a]);
-                binCnt[a][b]++;
-                binBox[a][b].grow(primBox[p]);
+        struct Bins { Box box[3][kBins]; uint32_t cnt[3][kBins]; };
+        auto sweepBins = [&](uint32_t b, uint32_t e, Box (*bx)[kBins], uint32_t (*bc)[kBins]) {
+            for (uint32_t i = b; i < e; i++) {
+                const uint32_t p = order[i];
+                for (int a = 0; a < 3; a++) {
+                    if (!live[a]) continue;
+                    const int bin = binOf(p, a, cb.mn[a], scale[a]);
+                    bc[a][bin]++;
+                    bx[a][bin].grow(primBox[p]);
+                }
             }
+        };
+        if (nChunks == 1u) {
+            sweepBins(first, first + count, binBox, binCnt);
+        } else {
+            std::vector<Bins> part(nChunks);
+#pragma omp taskloop grainsize(1) shared(part)
+            for (uint32_t c = 0; c < nChunks; c++) {
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < kBins; b++) { part[c].box[a][b].clear(); part[c].cnt[a][b] = 0; }
+                const uint32_t b = first + c * chunkLen, e = std::min(first + count, b + chunkLen);
+                sweepBins(b, e, part[c].box, part[c].cnt);
+            }
+            for (uint32_t c = 0; c < nChunks; c++)
+                for (int a = 0; a < 3; a++)
+                    for (int b = 0; b < kBins; b++) {
+                        binBox[a][b].grow(part[c].box[a][b]);
+                        binCnt[a][b] += part[c].cnt[a][b];
+                    }
         }
         // ---- evaluate the 3 x 15 planes: axis ascending, plane ascending, first strict minimum wins
         float bestCost = std::numeric_limits<float>::infinity();
@@ -133,12 +186,49 @@ struct Builder {
         if (bestAxis >= 0) {
             uint32_t nl = 0, nr = 0;
             const float lo = cb.mn[bestAxis], sc = scale[bestAxis];
-            for (uint32_t i = first; i < first + count; i++) { // stable partition
-                const uint32_t p = order[i];
-                if (binOf(p, bestAxis, lo, sc) < bestPlane) order[first + nl++] = p;
-                else scratch[first + nr++] = p;
+            if (nChunks == 1u) {
+                for (uint32_t i = first; i < first + count; i++) { // stable partition
+                    const uint32_t p = order[i];
+                    if (binOf(p, bestAxis, lo, sc) < bestPlane) order[first + nl++] = p;
+                    else scratch[first + nr++] = p;
+                }
+                crt::copyBytes(order + first + nl, scratch + first, sizeof(uint32_t) * nr);
+            } else {
+                // stable partition in three chunk-parallel steps: count the lefts of every chunk, place every element at its
+                // final position in scratch (lefts of chunk c after the lefts of chunks < c, rights likewise), copy back
+                std::vector<uint32_t> lefts(nChunks);
+#pragma omp taskloop grainsize(1) shared(lefts)
+                for (uint32_t c = 0; c < nChunks; c++) {
+                    const uint32_t b = first + c * chunkLen, e = std::min(first + count, b + chunkLen);
+                    uint32_t k = 0;
+                    for (uint32_t i = b; i < e; i++) k += binOf(order[i], bestAxis, lo, sc) < bestPlane ? 1u : 0u;
+                    lefts[c] = k;
+                }
+                std::vector<uint32_t> lOff(nChunks), rOff(nChunks);
+                for (uint32_t c = 0; c < nChunks; c++) {
+                    const uint32_t b = c * chunkLen, e = std::min(count, b + chunkLen);
+                    lOff[c] = nl;
+                    rOff[c] = nr;
+                    nl += lefts[c];
+                    nr += (e - b) - lefts[c];
+                }
+                const uint32_t totalLeft = nl;
+#pragma omp taskloop grainsize(1) shared(lOff, rOff)
+                for (uint32_t c = 0; c < nChunks; c++) {
+                    const uint32_t b = first + c * chunkLen, e = std::min(first + count, b + chunkLen);
+                    uint32_t l = first + lOff[c], r = first + totalLeft + rOff[c];
+                    for (uint32_t i = b; i < e; i++) {
+                        const uint32_t p = order[i];
+                        if (binOf(p, bestAxis, lo, sc) < bestPlane) scratch[l++] = p;
+                        else scratch[r++] = p;
+                    }
+                }
+#pragma omp taskloop grainsize(1)
+                for (uint32_t c = 0; c < nChunks; c++) {
+                    const uint32_t b = first + c * chunkLen, e = std::min(first + count, b + chunkLen);
+                    crt::copyBytes(order + b, scratch + b, sizeof(uint32_t) * (e - b));
+                }
             }
-            crt::copyBytes(order + first + nl, scratch + first, sizeof(uint32_t) * nr);
             nLeft = nl;
             const uint64_t cap = static_cast<uint64_t>(kLeafMax) << (kMaxDepth - depth - 1);
             if (static_cast<uint64_t>(nl > nr ? nl : nr) > cap) nLeft = 0;
@@ -176,6 +266,26 @@ void writeNode(crt_bvh_node& d, const TempNode& s)
 
 // Flatten the meshes in InstanceID order: triangle records {v0, e1, e2, ids}, shading records, and per triangle its
 // bounds (6 floats: min xyz, max xyz) and box centroid (3 floats) -- 9 floats per triangle in boxCent.
+// Threads this process can really use: OpenMP's default is the machine's CPU count, but a container often grants a share
+// (cgroup v2 cpu.max) -- 256 threads on a 16-CPU share made the 1M-triangle build 20-40 % slower and erratic.
+int usableThreads()
+{
+    static const int cached = [] {
+        int n = omp_get_max_threads();
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) n = std::min(n, CPU_COUNT(&set));
+        if (FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char quota[32] = { 0 };
+            long long period = 0;
+            if (std::fscanf(f, "%31s %lld", quota, &period) == 2 && std::strcmp(quota, "max") != 0 && period > 0)
+                n = std::min(n, std::max(1, static_cast<int>((std::atof(quota) / static_cast<double>(period)) + 0.5)));
+            std::fclose(f);
+        }
+        return std::max(1, n);
+    }();
+    return cached;
+}
+
 void flattenMeshes(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<crt_bvh_tri>& inTri, std::vector<crt_bvh_shade>& inShade,
                    std::vector<float>& boxCent)
 {
@@ -194,7 +304,7 @@ void flattenMeshes(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<c
     for (uint32_t m = 0; m < n_meshes; m++) {
         const crt_mesh_view& M = meshes[m];
         const long long nt = static_cast<long long>(M.n_triangles);
-#pragma omp parallel for schedule(static) if (nt > 65536) reduction(|| : bad)
+#pragma omp parallel for schedule(static) if (nt > 65536) reduction(|| : bad) num_threads(usableThreads())
         for (long long tt = 0; tt < nt; tt++) {
             const uint32_t t = static_cast<uint32_t>(tt), g = g0 + t;
             const uint32_t i0 = M.idx[3 * t], i1 = M.idx[3 * t + 1], i2 = M.idx[3 * t + 2];
@@ -265,11 +375,20 @@ void reorderUvs(const std::vector<crt_bvh_uv>& inUv, Bvh& bvh)
 
 void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
 {
+    const bool timing = std::getenv("CRT_BUILD_TIMING") != nullptr; // phase breakdown on stderr
+    auto tlast = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[sah build] %-24s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tlast).count());
+        tlast = t;
+    };
     std::vector<crt_bvh_tri> inTri;
     std::vector<crt_bvh_shade> inShade;
     std::vector<float> boxCent;
     flattenMeshes(meshes, n_meshes, inTri, inShade, boxCent);
     const uint32_t n = static_cast<uint32_t>(inTri.size());
+    lap("flatten");
 
     out.nodes.clear();
     out.nodes4.clear();
@@ -300,10 +419,12 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
     B.pool = pool.data();
     Box rootBox;
     int32_t root = 0;
-#pragma omp parallel
+    lap("setup arrays");
+#pragma omp parallel num_threads(usableThreads())
 #pragma omp single
     root = B.build(0, n, 0, rootBox);
     out.maxDepth = B.deepest.load();
+    lap("recursive build");
 
     if (root < 0) {
         // the whole scene fits one leaf: node 0 must exist, so wrap it; the right child is an empty leaf
@@ -338,13 +459,16 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
         }
     }
 
+    lap("renumber");
     out.tris.resize(n);
     out.shade.resize(n);
     for (uint32_t i = 0; i < n; i++) {
         out.tris[i] = inTri[order[i]];
         out.shade[i] = inShade[order[i]];
     }
+    lap("reorder records");
     collapseBvh4(out);
+    lap("collapse");
     std::vector<crt_bvh_uv> inUv;
     flattenUvs(meshes, n_meshes, inUv);
     reorderUvs(inUv, out);

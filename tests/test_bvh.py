@@ -118,6 +118,22 @@ def test_large_scene_parallel_build_is_deterministic(pkg, oracle, scenes):
     _compare(pkg, oracle, sc["meshes"])
 
 
+def test_chunk_parallel_sweeps_equal_the_serial_build(pkg, oracle, scenes):
+    """Ranges of >= 131072 triangles sweep bounds / bins / the stable partition in parallel chunks (the top levels of the
+    tree): same bytes as the oracle's plain recursive build, on a mesh whose triangle order is shuffled so that the
+    partition really has to keep it stable."""
+    sc = scenes.heightfield(n=330)  # 217 802 triangles
+    m = sc["meshes"][0]
+    rng = np.random.default_rng(5)
+    perm = rng.permutation(len(m["triangles"]))
+    meshes = [dict(m, triangles=np.ascontiguousarray(m["triangles"][perm]))] + sc["meshes"][1:]
+    nodes, tris, shade, md = pkg.build_bvh_host(meshes)
+    O = oracle.OracleScene(meshes)
+    assert nodes.tobytes() == O.nodes().tobytes() and tris.tobytes() == O.tris().tobytes() and shade.tobytes() == O.shade().tobytes()
+    nodes4, depth4 = pkg.build_bvh4_host(meshes)
+    assert nodes4.tobytes() == O.nodes4().tobytes() and depth4 == O.depth4
+
+
 def test_edge_cases(pkg, oracle):
     f = np.float32
     tri = f([(0, 0, 0), (1, 0, 0), (0, 1, 0)])
