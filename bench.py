@@ -213,14 +213,17 @@ def main():
     kernel_ms = float(np.median(kms))
 
     # PCIe-inclusive variant (host output buffer handed over the C ABI), for DESIGN.md; never `value`
-    d2h_ms = None
+    d2h_ms = d2h_pinned_ms = None
     if not multi:
         r.reset_stream()
-        r.render_frame(W, H, want=())
-        t0 = time.perf_counter()
-        for _ in range(5):
-            r.render_frame(W, H, want=())
-        d2h_ms = (time.perf_counter() - t0) / 5 * 1e3
+        d2h = {}
+        for pinned in (False, True):  # pageable numpy buffer vs page-locked crt_host_alloc buffer
+            r.render_frame(W, H, want=(), pinned=pinned)
+            t0 = time.perf_counter()
+            for _ in range(5):
+                r.render_frame(W, H, want=(), pinned=pinned)
+            d2h[pinned] = (time.perf_counter() - t0) / 5 * 1e3
+        d2h_ms, d2h_pinned_ms = d2h[False], d2h[True]
         r.set_stream(stream.cuda_stream)
 
     if rank == 0:
@@ -264,6 +267,7 @@ def main():
                                 "note": "bytes = 128 B x wide-node records fetched + 48 B x triangle records fetched + 4 B x pixels; "
                                         "the 113 MB working set is served mostly by L2 / Infinity Cache, so achieved may exceed what HBM itself moves"}
             line["ms_per_frame_incl_d2h"] = d2h_ms
+            line["ms_per_frame_incl_d2h_pinned"] = d2h_pinned_ms
             if not args.no_cpu_baseline:
                 line["cpu_baseline"] = cpu_baseline(entry.load_oracle(), sc)
                 line["speedup_vs_cpu_baseline"] = value / line["cpu_baseline"]["value"]

@@ -37,7 +37,7 @@ ABI_SYMBOLS = [
     "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_set_option", "crt_debug_read_timeline", "crt_debug_read_counters", "crt_render_frame", "crt_render_frame_device",
     "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_render_frames_batch_device", "crt_render_tiles_batch_device",
     "crt_untile_device", "crt_untile_batch_device", "crt_set_stream", "crt_reset_stream",
-    "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_build_host4", "crt_build_stats",
+    "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_host_alloc", "crt_host_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_build_host4", "crt_build_stats",
     "crt_scene_load", "crt_scene_save", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
     "crt_scene_add_material", "crt_scene_mesh_count", "crt_scene_mesh", "crt_scene_light_count", "crt_scene_light",
     "crt_scene_material_count", "crt_scene_material", "crt_scene_texture_count", "crt_scene_texture_color", "crt_scene_add_texture",
@@ -147,6 +147,8 @@ def lib():
         "crt_bvh_build_host": (C.c_int, [vp, u32, C.POINTER(vp), C.POINTER(u32), C.POINTER(vp), C.POINTER(vp),
                                          C.POINTER(u32), C.POINTER(u32)]),
         "crt_free": (None, [vp]),
+        "crt_host_alloc": (vp, [C.c_size_t]),
+        "crt_host_free": (None, [vp]),
         "crt_bvh_info4": (C.c_int, [vp, C.POINTER(u32), C.POINTER(u32)]),
         "crt_build_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "crt_bvh_export4": (C.c_int, [vp, vp]),
@@ -477,6 +479,7 @@ class Renderer:
 
     def close(self):
         if getattr(self, "h", None):
+            self._free_pinned()
             lib().crt_destroy(self.h)
             self.h = None
 
@@ -606,9 +609,28 @@ class Renderer:
         self._ok(lib().crt_bvh_export4(self.h, nodes4.ctypes.data), "crt_bvh_export4")
         return nodes4, b.value
 
-    def render_frame(self, w, h, want=("rgba8", "hit_inst", "hit_prim", "hit_t", "rgb")):
-        """renderFrame with host outputs. Returns dict of arrays + 'stats'."""
-        out = {"rgba8": np.zeros((h, w, 4), dtype=np.uint8)}
+    def pinned_frame(self, w, h):
+        """RGBA8 frame buffer in page-locked host memory (crt_host_alloc), reused across calls of render_frame(pinned=True)."""
+        key = (w, h)
+        if getattr(self, "_pinned_key", None) != key:
+            self._free_pinned()
+            ptr = lib().crt_host_alloc(w * h * 4)
+            if not ptr:
+                raise CrtError("crt_host_alloc failed")
+            self._pinned_ptr, self._pinned_key = ptr, key
+            self._pinned = np.ctypeslib.as_array((C.c_uint8 * (w * h * 4)).from_address(ptr)).reshape(h, w, 4)
+        return self._pinned
+
+    def _free_pinned(self):
+        if getattr(self, "_pinned_ptr", None):
+            self._pinned = None
+            lib().crt_host_free(self._pinned_ptr)
+            self._pinned_ptr, self._pinned_key = None, None
+
+    def render_frame(self, w, h, want=("rgba8", "hit_inst", "hit_prim", "hit_t", "rgb"), pinned=False):
+        """renderFrame with host outputs. Returns dict of arrays + 'stats'. pinned=True: rgba8 lands in a reused page-locked
+        buffer (valid until the next such call)."""
+        out = {"rgba8": self.pinned_frame(w, h) if pinned else np.zeros((h, w, 4), dtype=np.uint8)}
         if "hit_inst" in want:
             out["hit_inst"] = np.zeros((h, w), dtype=np.uint32)
         if "hit_prim" in want:

@@ -430,6 +430,18 @@ int crt_bvh_build_host(const crt_mesh_view* meshes, uint32_t n_meshes, crt_bvh_n
 
 void crt_free(void* p) { std::free(p); }
 
+void* crt_host_alloc(size_t bytes)
+{
+    void* p = nullptr;
+    if (bytes == 0 || hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr;
+    return p;
+}
+
+void crt_host_free(void* p)
+{
+    if (p) (void)hipHostFree(p);
+}
+
 int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes, const crt_light* lights, uint32_t n_lights,
                      const crt_material* materials, uint32_t n_materials)
 {

@@ -215,6 +215,12 @@ int crt_bvh_build_host(const crt_mesh_view* meshes, uint32_t n_meshes,
 int crt_bvh_build_host4(const crt_mesh_view* meshes, uint32_t n_meshes, crt_bvh_node4** nodes4, uint32_t* n_nodes4, uint32_t* depth4);
 void crt_free(void* p);
 
+/* page-locked host memory for crt_render_frame's output buffers: the device-to-host copy of a frame then runs at PCIe speed
+ * instead of through the driver's staging of pageable memory (8.3 MB at 1080p: 0.36 -> 0.17 ms).  Optional: any host
+ * pointer works.  Needs a HIP device; NULL on failure.  Release with crt_host_free. */
+void* crt_host_alloc(size_t bytes);
+void crt_host_free(void* p);
+
 /* ---------------------------------------------------------------------------------------------------
  * Scene layer: stands in for CRTScene / CRTSceneParser / CRTCamera (kept API surface, host only, no GPU)
  * ------------------------------------------------------------------------------------------------- */

@@ -180,6 +180,20 @@ def test_tile_partition_reassembles_full_frame(pkg, scenes, dragon, renderer):
             assert np.array_equal(host.reshape(-1), full.cpu().numpy().view(np.uint32))
 
 
+def test_pinned_host_frame(pkg, oracle, scenes, renderer):
+    """crt_host_alloc: a page-locked output buffer gives the same frame as a pageable one"""
+    sc = scenes.cornell_box()
+    cam = sc["camera"]
+    renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+    renderer.set_camera(cam["position"], cam["matrix"])
+    renderer.change_shading_mode(100)
+    a = renderer.render_frame(200, 120, want=())["rgba8"].copy()
+    b = renderer.render_frame(200, 120, want=(), pinned=True)["rgba8"].copy()
+    c = renderer.render_frame(64, 32, want=(), pinned=True)["rgba8"].copy()  # size change reallocates
+    assert np.array_equal(a, b) and c.shape == (32, 64, 4)
+    assert np.array_equal(a, oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"]).render(cam["position"], cam["matrix"], 100, 200, 120)["rgba8"])
+
+
 def test_external_stream_and_error_paths(pkg, scenes, renderer):
     import torch
     r2 = pkg.Renderer(0)
