@@ -179,7 +179,8 @@ int crt_untile_batch_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint3
  * Rendering parameters of mode 200: "spp", "max_bounces", "seed". Tuning knobs (speed only, results never
  * change): "inner_min" 1..65 wave scheduling of the traversal loop, "xcd_group", "adaptive_order" (launch the most expensive 8x8
  * packets of the previous frame first: 0 never, 1 always, 2 = default: only for a frame issued on the same stream as the frame
- * before, where frames run one after another), "boost_units", "stack_entries" (0 = default 24; deeper entries spill to a
+ * before, where frames run one after another), "remeasure_every" (a moving camera re-measures packet costs every n-th use of a scratch slot; default 1), "boost_units",
+ * "stack_entries" (0 = default 24; deeper entries spill to a
  * global arena). Diagnostics: "timeline" 0/1, "debug_skip_units". */
 int crt_set_option(crt_ctx* ctx, const char* name, int value);
 
