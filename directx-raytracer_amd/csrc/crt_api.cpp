@@ -85,6 +85,7 @@ struct crt_ctx {
     uint32_t tuneRemeasureEvery = 1; // a changing view re-measures at every use of a slot: stale orders cost more than the measuring (tools/moving_camera.py)
     uint32_t viewSerial = 1;         // bumped when camera, mode or path settings change: costs must be measured again
     bool renderPending[kRing] = {};  // evRender[slot] recorded
+    hipStream_t slotStream[kRing] = {}; // stream the slot's last frame ran on
     uint32_t frameSerial = 0;
     hipStream_t sideStream = nullptr; // sorts the costs of frame f while later frames render
     hipEvent_t evRender[kRing] = {}, evSort[kRing] = {};
@@ -274,9 +275,13 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
     }
     // the previous user of this slot (frame f - kRing, possibly on another stream) and the sort of its costs must be done
     // before this frame touches the slot's spill arena, cost or order buffer
-    if (c->sortPending[slot]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evSort[slot], 0));
-    if (c->renderPending[slot]) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evRender[slot], 0));
+    // (a wait is only enqueued when it can matter: not for an event that has already completed, not for a frame that ran on
+    // this same stream -- every barrier packet costs the stream a few microseconds)
+    if (c->sortPending[slot] && hipEventQuery(c->evSort[slot]) != hipSuccess) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evSort[slot], 0));
+    if (c->renderPending[slot] && c->slotStream[slot] != c->stream && hipEventQuery(c->evRender[slot]) != hipSuccess)
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evRender[slot], 0));
     c->sortPending[slot] = false;
+    c->slotStream[slot] = c->stream;
     if (stats) HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     const int rc = crt::launchRender(p, counting, c->stream);
     if (rc != 0) return fail(c, CRT_EHIP, "render kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));

@@ -21,7 +21,7 @@ def cam(i):
     return (R @ pos0).astype(np.float32), (R @ np.float32(sc["camera"]["matrix"]).reshape(3, 3)).astype(np.float32).reshape(9)
 for moving, every in ((False, 1), (True, 1), (True, 2), (True, 8), (True, 32), (False, 1)):
     r.set_option("remeasure_every", every)
-    r.set_camera(*cam(0))
+    r.set_camera(*cam(130))  # the static reference view = the middle of the orbit segment the moving runs cover (30..230)
     for i in range(30):
         if moving: r.set_camera(*cam(i))
         r.render_frame_device(W, H, frame.data_ptr())
