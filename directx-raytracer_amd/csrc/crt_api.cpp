@@ -82,6 +82,7 @@ struct crt_ctx {
     uint32_t orderView[kRing] = {};  // viewSerial the stored order was measured under
     uint32_t orderGen[kRing] = {};   // consecutive measurements of this frame geometry
     uint32_t orderFrame[kRing] = {}; // frameSerial of the last measurement
+    bool debugForceMeasure = false;  // diagnostics: measure and sort at every frame even for an unchanged view
     uint32_t tuneRemeasureEvery = 1; // a changing view re-measures at every use of a slot: stale orders cost more than the measuring (tools/moving_camera.py)
     uint32_t viewSerial = 1;         // bumped when camera, mode or path settings change: costs must be measured again
     bool renderPending[kRing] = {};  // evRender[slot] recorded
@@ -265,7 +266,7 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         const bool twice = usable && c->orderGen[slot] >= 2;
         const bool sameView = c->orderView[slot] == c->viewSerial;
         const bool recent = (c->frameSerial - c->orderFrame[slot]) < static_cast<uint32_t>(crt_ctx::kRing) * c->tuneRemeasureEvery;
-        if (!(twice && (sameView || recent))) {
+        if (c->debugForceMeasure || !(twice && (sameView || recent))) {
             p.unit_cost = c->dUnitCost[slot];
             feedback = true;
             c->orderGen[slot] = usable ? c->orderGen[slot] + 1 : 1;
@@ -623,6 +624,10 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
     }
     if (std::strcmp(name, "timeline") == 0) {
         c->wantTimeline = value != 0;
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "debug_force_measure") == 0) {
+        c->debugForceMeasure = value != 0;
         return CRT_OK;
     }
     if (std::strcmp(name, "remeasure_every") == 0 && value >= 1 && value <= 1024) {
