@@ -19,8 +19,9 @@ def cam(i):
     c, s = np.cos(a), np.sin(a)
     R = np.float32([[c, 0, s], [0, 1, 0], [-s, 0, c]])
     return (R @ pos0).astype(np.float32), (R @ np.float32(sc["camera"]["matrix"]).reshape(3, 3)).astype(np.float32).reshape(9)
-for moving, every in ((False, 1), (True, 1), (True, 2), (True, 8), (True, 32), (False, 1)):
-    r.set_option("remeasure_every", every)
+for moving, every in ((False, 1), (False, -1), (True, 1), (True, 2), (True, 8), (True, 32), (False, 1)):
+    r.set_option("debug_force_measure", 1 if every < 0 else 0)  # -1: static view, but measured and sorted at every frame
+    r.set_option("remeasure_every", abs(every))
     r.set_camera(*cam(130))  # the static reference view = the middle of the orbit segment the moving runs cover (30..230)
     for i in range(30):
         if moving: r.set_camera(*cam(i))
