@@ -651,13 +651,25 @@ def test_random_scenes_property(pkg, oracle, scenes, renderer):
         v = np.float32(tris).reshape(-1, 3)
         t = np.arange(len(v), dtype=np.uint32).reshape(-1, 3)
         cut = [len(t) * k // n_meshes for k in range(n_meshes + 1)]
-        meshes = [{"vertices": v, "triangles": t[cut[k]:cut[k + 1]], "material_index": k % 3} for k in range(n_meshes) if cut[k + 1] > cut[k]]
-        mats = [{"albedo": (0.8, 0.7, 0.6), "type": 1}, {"albedo": (0.9, 0.9, 0.9), "type": 2}, {"albedo": (1.0, 1.0, 1.0), "type": 3, "ior": 1.5}]
+        meshes = [{"vertices": v, "triangles": t[cut[k]:cut[k + 1]], "material_index": k % 4} for k in range(n_meshes) if cut[k + 1] > cut[k]]
+        # seeded extras: smooth-shading normals, per-vertex uvs (outside [0,1] too) and one texture of a random kind
+        g = np.random.default_rng(seed)
+        nrm = g.normal(size=v.shape).astype(np.float32)
+        nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-6).astype(np.float32)
+        uv = np.concatenate([g.uniform(-1.5, 2.5, size=(len(v), 2)), np.zeros((len(v), 1))], axis=1).astype(np.float32)
+        for m in meshes:
+            m["normals"] = nrm
+            m["uvs"] = uv
+        kind = ("albedo", "edges", "checker", "bitmap")[seed % 4]
+        tex = {"type": kind, "color_a": (0.9, 0.2, 0.1), "color_b": (0.1, 0.3, 0.9), "scalar": (0.07, 0.3, 1.0)[seed % 3],
+               "pixels": g.integers(0, 256, size=(5, 7, 3), dtype=np.uint8)}
+        mats = [{"albedo": (0.8, 0.7, 0.6), "type": 1, "texture": 0, "smooth_shading": bool(seed & 8)}, {"albedo": (0.9, 0.9, 0.9), "type": 2},
+                {"albedo": (1.0, 1.0, 1.0), "type": 3, "ior": 1.5}, {"albedo": (0.5, 0.9, 0.4), "type": 1, "smooth_shading": True}]
         lights = [((2.0, 5.0, 3.0), 300.0), ((-3.0, -2.0, 6.0), 150.0)]
         rot = scenes.camera_matrix(yaw_deg=float(ang[0]), pitch_deg=float(ang[1]))
-        renderer.upload(meshes, lights, mats)
+        renderer.upload(meshes, lights, mats, [tex])
         renderer.set_camera(pos, rot)
-        O = oracle.OracleScene(meshes, lights, mats)
+        O = oracle.OracleScene(meshes, lights, mats, textures=[tex])
         for mode in (3, 100, pkg.MODE_PATH):
             renderer.change_shading_mode(mode)
             if mode == pkg.MODE_PATH:
