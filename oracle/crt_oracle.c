@@ -20,6 +20,7 @@
  */
 #include "crt_oracle.h"
 
+#include <immintrin.h>
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
@@ -818,14 +819,35 @@ static int trace_any2(const oracle_scene* s, const ray* r, float tmin, float tma
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
+/* the four slab tests of a wide node in one SSE pass: lane k = child k.  _mm_min_ps(a, b) is exactly minf_(a, b) = a < b ? a : b
+ * (and max likewise), _mm_fmadd_ps is fmaf per lane: bit for bit box_test() applied to each child.  Returns the hit mask. */
+static inline int slab4(const oracle_node4* N, const ray* r, float tmin, float tcull, float tn_out[4])
+{
+    const __m128 ix = _mm_set1_ps(r->idir.x), iy = _mm_set1_ps(r->idir.y), iz = _mm_set1_ps(r->idir.z);
+    const __m128 ox = _mm_set1_ps(r->noid.x), oy = _mm_set1_ps(r->noid.y), oz = _mm_set1_ps(r->noid.z);
+    const __m128 ax = _mm_fmadd_ps(_mm_loadu_ps(N->minx), ix, ox), bx = _mm_fmadd_ps(_mm_loadu_ps(N->maxx), ix, ox);
+    const __m128 ay = _mm_fmadd_ps(_mm_loadu_ps(N->miny), iy, oy), by = _mm_fmadd_ps(_mm_loadu_ps(N->maxy), iy, oy);
+    const __m128 az = _mm_fmadd_ps(_mm_loadu_ps(N->minz), iz, oz), bz = _mm_fmadd_ps(_mm_loadu_ps(N->maxz), iz, oz);
+    const __m128 tn = _mm_max_ps(_mm_max_ps(_mm_min_ps(ax, bx), _mm_min_ps(ay, by)), _mm_max_ps(_mm_min_ps(az, bz), _mm_set1_ps(tmin)));
+    const __m128 tf = _mm_min_ps(_mm_min_ps(_mm_max_ps(ax, bx), _mm_max_ps(ay, by)), _mm_min_ps(_mm_max_ps(az, bz), _mm_set1_ps(tcull)));
+    _mm_storeu_ps(tn_out, tn);
+    const __m128i empty = _mm_cmpeq_epi32(_mm_loadu_si128((const __m128i*)N->ref), _mm_set1_epi32((int)ORACLE_EMPTY));
+    return _mm_movemask_ps(_mm_andnot_ps(_mm_castsi128_ps(empty), _mm_cmple_ps(tn, tf)));
+}
+
 static inline int wide_step(const oracle_node4* N, const ray* r, float tmin, float tcull, uint32_t key[4])
 {
+    float tn[4];
+    const int mask = slab4(N, r, tmin, tcull, tn);
+    if (mask == 0) return 0;
+    if ((mask & (mask - 1)) == 0) { /* one child hit: nothing to order (same outcome as the network below) */
+        key[0] = (uint32_t)__builtin_ctz((unsigned)mask);
+        return 1;
+    }
     int n_hit = 0;
     for (int k = 0; k < 4; k++) {
-        float tn;
-        int hit = box_test(N->minx[k], N->maxx[k], N->miny[k], N->maxy[k], N->minz[k], N->maxz[k], r, tmin, tcull, &tn);
-        hit &= N->ref[k] != ORACLE_EMPTY;
-        key[k] = hit ? ((f2u(tn) & 0x7FFFFFFCu) | (uint32_t)k) : 0xFFFFFFFFu;
+        const int hit = (mask >> k) & 1;
+        key[k] = hit ? ((f2u(tn[k]) & 0x7FFFFFFCu) | (uint32_t)k) : 0xFFFFFFFFu;
         n_hit += hit;
     }
     /* sorting network (0,1)(2,3)(0,2)(1,3)(1,2), ascending */
@@ -889,10 +911,10 @@ static int trace_any4(const oracle_scene* s, const ray* r, float tmin, float tma
             c->nodes++;
             int first_hit = -1;
             int hits[4];
+            float tn4[4];
+            const int mask = slab4(N, r, tmin, tcull, tn4);
             for (int k = 0; k < 4; k++) {
-                float tn;
-                hits[k] = box_test(N->minx[k], N->maxx[k], N->miny[k], N->maxy[k], N->minz[k], N->maxz[k], r, tmin, tcull, &tn) &
-                          (N->ref[k] != ORACLE_EMPTY);
+                hits[k] = (mask >> k) & 1;
                 if (hits[k] && first_hit < 0) first_hit = k;
             }
             if (first_hit >= 0) {
