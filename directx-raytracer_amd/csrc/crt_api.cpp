@@ -240,8 +240,7 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
     c->haveLastRenderStream = true;
     if ((c->adaptiveOrder == 1 || (c->adaptiveOrder == 2 && sameStream)) && nUnits) {
         if (c->unitCapacity < nUnits) {
-            HIP_TRY(c, hipStreamSynchronize(c->sideStream));
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            HIP_TRY(c, hipDeviceSynchronize()); // (frames of other streams may still use the buffers about to be replaced)
             for (int i = 0; i < crt_ctx::kRing; i++) {
                 if (c->dUnitCost[i]) (void)hipFree(c->dUnitCost[i]);
                 if (c->dUnitOrder[i]) (void)hipFree(c->dUnitOrder[i]);
@@ -393,7 +392,7 @@ void crt_destroy(crt_ctx* c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    (void)hipDeviceSynchronize(); // frames may still be in flight on streams the caller set earlier, not only on the current one
     freeScene(c);
     for (int i = 0; i < 5; i++)
         if (c->dFrame[i]) (void)hipFree(c->dFrame[i]);
@@ -476,7 +475,7 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
         return fail(c, CRT_EINVAL, "BVH build failed: %s", ex.what());
     }
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipDeviceSynchronize()); // frames in flight on any stream the caller used still read the old scene's buffers
     freeScene(c);
     const size_t nb = sizeof(crt_bvh_node4) * c->bvh.nodes4.size(); // the wide tree is what the kernels traverse
     const size_t tb = sizeof(crt_bvh_tri) * c->bvh.tris.size();
