@@ -21,6 +21,16 @@
 
 using crt::RenderParams;
 
+// Diagnostics that change what a frame does or costs ("timeline", "debug_skip_units", "debug_force_measure") exist only in
+// the diagnostic builds (tools/diag_build.sh, tools/prof_build.sh: -DCRT_DIAG=1); the product rejects the option names.
+#ifndef CRT_DIAG
+#ifdef CRT_PROF
+#define CRT_DIAG 1
+#else
+#define CRT_DIAG 0
+#endif
+#endif
+
 struct crt_scene {
     crt::Scene scene;
     // uint32 copies of the int index vectors are not needed: std::vector<int> is reinterpreted like the
@@ -199,6 +209,7 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
 int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
 {
     const bool counting = c->counting;
+    HIP_TRY(c, hipSetDevice(c->device)); // the calling thread's current device may be another one (scratch hipMallocs below)
     if (counting) HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 16 * sizeof(unsigned long long), c->stream));
     if (c->wantTimeline && p.n_batch == 1) {
         const size_t words = 3 * (static_cast<size_t>(p.tiles_x + 4) * (p.tiles_y + 4) * 4 + 1024);
@@ -461,13 +472,14 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     if (!c) return CRT_EINVAL;
     if ((!meshes && n_meshes) || (!lights && n_lights) || (!materials && n_materials)) return fail(c, CRT_EINVAL, "NULL array with non-zero count");
     const auto tb0 = std::chrono::steady_clock::now();
-    c->buildDeviceMs = 0.0;
+    double deviceMs = 0.0;
+    crt::Bvh built; // swapped into the context only once the build has succeeded: a failed build leaves the old scene intact
     try {
         if (c->gpuBuild) {
             HIP_TRY(c, hipSetDevice(c->device));
-            crt::buildBvhGpu(meshes, n_meshes, c->bvh, c->stream, &c->buildDeviceMs);
+            crt::buildBvhGpu(meshes, n_meshes, built, c->stream, &deviceMs);
         } else {
-            crt::buildBvh(meshes, n_meshes, c->bvh);
+            crt::buildBvh(meshes, n_meshes, built);
         }
     } catch (const std::bad_alloc&) {
         return fail(c, CRT_ENOMEM, "out of host memory while building the BVH");
@@ -476,7 +488,9 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     }
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize()); // frames in flight on any stream the caller used still read the old scene's buffers
-    freeScene(c);
+    freeScene(c); // from here on a failure leaves NO scene (haveScene = false): never the new host tree over old device buffers
+    std::swap(c->bvh, built);
+    c->buildDeviceMs = deviceMs;
     const size_t nb = sizeof(crt_bvh_node4) * c->bvh.nodes4.size(); // the wide tree is what the kernels traverse
     const size_t tb = sizeof(crt_bvh_tri) * c->bvh.tris.size();
     const size_t sb = sizeof(crt_bvh_shade) * c->bvh.shade.size();
@@ -617,6 +631,7 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
         c->tuneBoostUnits = static_cast<uint32_t>(value);
         return CRT_OK;
     }
+#if CRT_DIAG
     if (std::strcmp(name, "debug_skip_units") == 0 && value >= 0) {
         c->debugSkipUnits = static_cast<uint32_t>(value);
         return CRT_OK;
@@ -629,6 +644,10 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
         c->debugForceMeasure = value != 0;
         return CRT_OK;
     }
+#else
+    if (std::strcmp(name, "debug_skip_units") == 0 || std::strcmp(name, "timeline") == 0 || std::strcmp(name, "debug_force_measure") == 0)
+        return fail(c, CRT_EINVAL, "option '%s' exists only in the diagnostic build (tools/diag_build.sh)", name);
+#endif
     if (std::strcmp(name, "remeasure_every") == 0 && value >= 1 && value <= 1024) {
         c->tuneRemeasureEvery = static_cast<uint32_t>(value);
         return CRT_OK;
@@ -649,6 +668,7 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
 int crt_debug_read_timeline(crt_ctx* c, unsigned long long* out, size_t max_words, size_t* n_words)
 {
     if (!c || !out || !n_words) return CRT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
     const size_t n = c->timelineWords < max_words ? c->timelineWords : max_words;
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (n) HIP_TRY(c, hipMemcpy(out, c->dTimeline, n * sizeof(unsigned long long), hipMemcpyDeviceToHost));
@@ -659,6 +679,7 @@ int crt_debug_read_timeline(crt_ctx* c, unsigned long long* out, size_t max_word
 int crt_debug_read_counters(crt_ctx* c, unsigned long long out[16])
 {
     if (!c || !out) return CRT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     HIP_TRY(c, hipMemcpy(out, c->dCounters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CRT_OK;
@@ -681,6 +702,7 @@ int crt_reset_stream(crt_ctx* c)
 int crt_synchronize(crt_ctx* c)
 {
     if (!c) return CRT_EINVAL;
+    HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return CRT_OK;
 }
@@ -812,6 +834,7 @@ int crt_untile_batch_device(crt_ctx* c, uint32_t w, uint32_t h, uint32_t n_ranks
     if (!d_gathered || !d_rgba8 || n_ranks == 0 || w == 0 || h == 0 || n_frames == 0 || frame >= n_frames)
         return fail(c, CRT_EINVAL, "crt_untile_batch_device: bad argument");
     const uint32_t slots = crt_tile_slots(w, h, n_ranks);
+    HIP_TRY(c, hipSetDevice(c->device));
     const int rc = crt::launchUntile(static_cast<const uint32_t*>(d_gathered), static_cast<uint32_t*>(d_rgba8), w, h, n_ranks,
                                      n_frames * slots, frame * slots, c->stream);
     if (rc != 0) return fail(c, CRT_EHIP, "untile kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));

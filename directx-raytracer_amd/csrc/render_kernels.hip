@@ -3,12 +3,12 @@
 // R/DXRTRenderer.cpp:1405) -- fused into one kernel, with the BVH traversal and the ray/triangle test the
 // reference leaves to the DXR driver written out.
 //
-// Mapping: one 256-thread workgroup = one 16x16-pixel macro tile = four wavefronts, each wavefront a coherent
-// 8x8-pixel ray packet.  Every lane owns one ray and a private traversal stack in LDS (entry e of thread t at
-// dword e*256+t: conflict free, no per-thread scratch memory, so the vector memory path only carries BVH data).
-// Nodes are 64-byte records (both child boxes in the parent) fetched as four dwordx4 loads, triangles 48-byte
-// records fetched as three.  Workgroups are dealt round-robin to the 8 XCDs; the tile index is remapped so
-// that each XCD works on a contiguous band of the frame and its private L2 keeps that band's subtrees.
+// Mapping: one 64-thread workgroup = one wavefront = one 8x8-pixel ray packet (the work unit); four units form the
+// 16x16 macro tile that is the unit of multi-GPU ownership.  Every lane owns one ray and a private traversal stack
+// in LDS (entry e of lane l at dword e*64+l: conflict free, 24 entries = 6 KB per wavefront; deeper entries spill
+// to a global arena).  The tree is 4-wide; a node is fetched per lane with dwordx4 loads, or once per wavefront
+// through the scalar cache when all lanes stand on the same node; triangles are 48-byte records.  Units are
+// launched most-expensive-first from the cost the previous frame measured.
 //
 // Arithmetic contract: identical, operation for operation, to oracle/crt_oracle.c (compiled with
 // -ffp-contract=off; fused multiply-adds only where fmaf()/fma() is written; correctly rounded / and sqrt).
@@ -35,6 +35,11 @@ constexpr uint32_t kBoostAfter = 300;
 #endif
 #ifndef CRT_PROF
 #define CRT_PROF 0
+#endif
+// diagnostics that change what a frame does or costs (per-workgroup timeline stamps, dropping the most expensive
+// packets): only in the diagnostic builds of tools/diag_build.sh / tools/prof_build.sh, never in the product
+#ifndef CRT_DIAG
+#define CRT_DIAG CRT_PROF
 #endif
 // Register budget: the primary/shadow-ray variant is asked for at least 6 wavefronts per SIMD (<= 80 VGPRs; it needs 78,
 // and the LDS stacks allow 26 wavefronts per CU).  7 (72 VGPRs, 36 B/lane spilled) measured 0.330 ms against 0.325,
@@ -894,7 +899,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
 {
     extern __shared__ int s_stack[]; // stack_entries x 256 dwords, sized at launch from the BVH depth
     unsigned long long t_start = 0;
-    if (p.timeline || p.unit_cost) t_start = __builtin_amdgcn_s_memrealtime();
+    if ((CRT_DIAG && p.timeline) || p.unit_cost) t_start = __builtin_amdgcn_s_memrealtime();
 
     // Work unit = one 8x8-pixel packet = one single-wavefront workgroup; unit u = 4 * j + sub, j = position of the 16x16
     // macro tile in this rank's tile list, sub = which 8x8 quarter.  Which unit a workgroup takes:
@@ -919,7 +924,9 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
         // the few packets with the longest critical paths bound the frame time even when they start first: let them
         // issue ahead of the other resident wavefronts
         if (b < p.boost_units) __builtin_amdgcn_s_setprio(3);
-        if (b < p.debug_skip_units) return; // diagnostics only: drop the most expensive packets to see what bounds the frame
+#if CRT_DIAG
+        if (b < p.debug_skip_units) return; // drop the most expensive packets to see what bounds the frame
+#endif
     } else {
         const uint32_t xcd = b & 7u, seq = b >> 3, i = seq >> 2;
         const uint32_t kGroup = p.xcd_group;
@@ -1020,14 +1027,16 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
     // cost fed back to order the next frame = this wavefront's lifetime in 0.64 us units (constant 100 MHz clock): it
     // sees what an iteration count does not (distant, incoherent packets are slow per iteration: cache misses)
     if (p.unit_cost && frame == 0u && threadIdx.x == 0) p.unit_cost[unit] = static_cast<uint32_t>((__builtin_amdgcn_s_memrealtime() - t_start) >> 6);
+#if CRT_DIAG
     if (p.timeline && threadIdx.x == 0) {
-        // diagnostic build only: wave lifetime on the constant 100 MHz clock, and which XCD ran it
+        // wave lifetime on the constant 100 MHz clock, and which XCD ran it
         const unsigned long long t_end = __builtin_amdgcn_s_memrealtime();
         const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu; // HW_REG_XCC_ID[3:0]
         p.timeline[3 * static_cast<size_t>(blockIdx.x) + 0] = t_start;
         p.timeline[3 * static_cast<size_t>(blockIdx.x) + 1] = t_end;
         p.timeline[3 * static_cast<size_t>(blockIdx.x) + 2] = (static_cast<unsigned long long>(xcc) << 32) | (tile_y << 16) | tile_x;
     }
+#endif
 #if CRT_PROF
     if (p.counters) {
         const unsigned long long tk = __builtin_amdgcn_s_memtime() - tk0;

@@ -181,10 +181,11 @@ int crt_untile_batch_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint3
  * packets of the previous frame first: 0 never, 1 always, 2 = default: only for a frame issued on the same stream as the frame
  * before, where frames run one after another), "remeasure_every" (a moving camera re-measures packet costs every n-th use of a scratch slot; default 1), "boost_units",
  * "stack_entries" (0 = default 24; deeper entries spill to a
- * global arena). Diagnostics: "timeline" 0/1, "debug_skip_units". */
+ * global arena). The diagnostic options "timeline", "debug_skip_units" and "debug_force_measure" (which do change what a frame
+ * does) exist only in the diagnostic build of the library (tools/diag_build.sh); the product returns CRT_EINVAL for them. */
 int crt_set_option(crt_ctx* ctx, const char* name, int value);
 
-/* diagnostics: with option "timeline" = 1 and counting enabled, a render records per workgroup {start, end} on the
+/* diagnostic build only (the product returns 0 words): with option "timeline" = 1 and counting enabled, a render records per workgroup {start, end} on the
  * 100 MHz s_memrealtime clock and (XCC id << 32 | tile_y << 16 | tile_x); this copies them out (3 words per workgroup) */
 int crt_debug_read_timeline(crt_ctx* ctx, unsigned long long* out, size_t max_words, size_t* n_words);
 /* raw device counters of the last counting render: [0] nodes [1] triangles [2] shadow rays [3] closest-hit rays; [4..10]

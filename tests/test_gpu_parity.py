@@ -180,6 +180,105 @@ def test_tile_partition_reassembles_full_frame(pkg, scenes, dragon, renderer):
             assert np.array_equal(host.reshape(-1), full.cpu().numpy().view(np.uint32))
 
 
+def test_c3_tiled_over_2_4_8_ranks_vs_oracle(pkg, oracle, scenes, renderer):
+    """BASELINE.json configs[3]: the 1M-triangle mesh at 1920x1080, framebuffer tiled over 2 / 4 / 8 ranks (every rank's
+    launch run on this one GPU), rank buffers laid out as the RCCL all-gather leaves them, de-interleaved by the untile
+    kernel: the reassembled frame must be the ORACLE's frame, pixel for pixel.  Replaces the reference's single
+    DispatchRays (R/DXRTRenderer.cpp:1346-1350, 1405)."""
+    import torch
+    sc = scenes.heightfield()
+    assert sum(len(m["triangles"]) for m in sc["meshes"]) == 1002530
+    cam = sc["camera"]
+    w, h = 1920, 1080
+    renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+    renderer.set_camera(cam["position"], cam["matrix"])
+    renderer.change_shading_mode(100)
+    ref = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"]).render(cam["position"], cam["matrix"], 100, w, h, want=("rgba8",))
+    ref = np.ascontiguousarray(ref["rgba8"]).view(np.uint32).reshape(-1)
+    for n in (2, 4, 8):
+        slots = pkg.tile_slots(w, h, n)
+        assert slots * 1024 == {2: 4177920, 4: 2088960, 8: 1044480}[n]  # bytes each rank contributes to the all-gather
+        gathered = torch.zeros(n * slots * 256, dtype=torch.int32, device="cuda")
+        frame = torch.zeros(h * w, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        rays = 0
+        for rank in range(n):
+            rays += renderer.render_tiles_device(w, h, rank, n, gathered.data_ptr() + rank * slots * 1024, stats=True)["rays_primary"]
+        assert rays == w * h  # the ranks' shares partition the frame
+        renderer.untile_device(w, h, n, gathered.data_ptr(), frame.data_ptr())
+        renderer.synchronize()
+        np.testing.assert_array_equal(frame.cpu().numpy().view(np.uint32), ref, err_msg="n_ranks=%d" % n)
+        # batched variant (2 frames per launch, as bench.py's pipelined policy uses from 8 ranks up): same frames
+        if n == 8:
+            g2 = torch.zeros(n * 2 * slots * 256, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            for rank in range(n):
+                base = g2.data_ptr() + rank * 2 * slots * 1024
+                renderer.render_tiles_batch_device(w, h, rank, n, [base, base + slots * 1024])
+            for f in range(2):
+                renderer.untile_batch_device(w, h, n, 2, f, g2.data_ptr(), frame.data_ptr())
+                renderer.synchronize()
+                np.testing.assert_array_equal(frame.cpu().numpy().view(np.uint32), ref, err_msg="batched frame %d" % f)
+
+
+def test_rccl_gather_path_of_bench_in_a_fresh_process():
+    """The real N>1 code path of bench.py -- RCCL communicator init, tile staging, ONE all-gather per launch, de-interleave --
+    in a fresh child process with world size 1 (all this box has); the child compares the gathered frame with the oracle's
+    and exits non-zero on any difference.  Both pipelining policies run (1 launch in flight, and 4 in flight)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "6", "--warmup", "2",
+                          "--check-dist-frame"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["frame_matches_oracle"] is True
+    assert line["config"]["launches_in_flight"] == 1 and line["config"]["frames_per_launch"] == 1
+    assert line["pipelined"]["launches_in_flight"] == 4 and line["pipelined"]["value"] > 0
+    assert "all-gather" in line["config"]["parallelism"] or line["n_gpus"] == 1
+
+
+def test_obj_scene_renders_like_the_oracle(pkg, oracle, scenes, renderer, tmp_path):
+    """north_star: "so the same .obj scenes render": a Wavefront .obj written here (two objects, quads and triangles,
+    negative and v/vt/vn index forms) goes through crt_scene_load -> crt_upload_scene_from -> the HIP kernels; the frames
+    equal the oracle's on the arrays the loader produced."""
+    sp = scenes.displaced_sphere(n_lat=24, n_lon=32)["meshes"][1]  # the sphere (mesh 0 is its ground quad)
+    lines = ["# written by tests/test_gpu_parity.py", "o blob"]
+    lines += ["v %.9g %.9g %.9g" % tuple(float(c) for c in v) for v in sp["vertices"]]
+    nv = len(sp["vertices"])
+    for i, t in enumerate(sp["triangles"]):
+        a, b, c = (int(x) for x in t)
+        if i % 3 == 0:
+            lines.append("f %d %d %d" % (a + 1, b + 1, c + 1))
+        elif i % 3 == 1:
+            lines.append("f %d %d %d" % (a - nv, b - nv, c - nv))                 # negative (relative) indices
+        else:
+            lines.append("f %d/1/1 %d/1/1 %d/1/1" % (a + 1, b + 1, c + 1))       # v/vt/vn form
+    lines += ["o floor", "v -20 -7 -20", "v 20 -7 -20", "v 20 -7 20", "v -20 -7 20", "f -4 -1 -2 -3"]  # a quad: split into two triangles
+    path = tmp_path / "blob.obj"
+    path.write_text("\n".join(lines) + "\n")
+    s = pkg.Scene(str(path))
+    assert s.mesh_count == 2 and len(s.mesh(1)["triangles"]) == 2
+    s.add_light((6.0, 9.0, 4.0), 900.0)
+    s.set_camera(pos=np.float32([0, 2, 16]), rot=scenes.camera_matrix(0.0, 8.0))
+    renderer.upload_scene(s)
+    renderer.set_camera_from(s)
+    pos, rot = s.camera()
+    meshes = [dict(vertices=m["vertices"], triangles=m["triangles"], normals=m["normals"], material_index=m["material_index"]) for m in s.meshes()]
+    O = oracle.OracleScene(meshes, s.lights(), s.materials())
+    for mode in (0, 3, 100):
+        renderer.change_shading_mode(mode)
+        got = renderer.render_frame(640, 360)
+        ref = O.render(pos, rot, mode, 640, 360)
+        for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
+            np.testing.assert_array_equal(got[k], ref[k], err_msg="mode %d %s" % (mode, k))
+        assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True)
+    assert (got["hit_inst"] == 0).any() and (got["hit_inst"] == 1).any()  # both objects are in view
+
+
 def test_pinned_host_frame(pkg, oracle, scenes, renderer):
     """crt_host_alloc: a page-locked output buffer gives the same frame as a pageable one"""
     sc = scenes.cornell_box()

@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """Condense a tools/profile.sh run (gpurun_out/prof_<tag>/) into the files committed under profiles/:
   profiles/<tag>_kernel_stats.csv   rocprofv3 --kernel-trace --stats summary (per-kernel calls / avg ns)
-  profiles/<tag>_pmc.json           per-launch medians of the PMC passes for the render kernel
-  profiles/hbm_traffic.json         HBM bytes per launch that bench.py reports as roofline.traffic
+  profiles/<tag>_pmc.json           per-launch medians of every PMC pass for the render kernel
+  profiles/roofline_inputs.json     per scene: what bench.py's roofline block reads (instruction counts, HBM / L2 bytes per launch)
 Counter handling follows /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB,
 collected in separate passes (TCC slots); on gfx950 FETCH_SIZE tallies 128-B requests of 16-B-per-lane loads at 64 B,
 so the read side is doubled; WRITE_SIZE is exact for dword-per-lane stores.
@@ -14,6 +14,7 @@ import json
 import os
 import shutil
 import statistics
+import subprocess
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -38,21 +39,39 @@ def main():
                 meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "Scratch_Size", "VGPR_Count", "Accum_VGPR_Count", "SGPR_Count")}
         for k, v in acc.items():
             med[k] = {"median": statistics.median(v), "min": min(v), "max": max(v), "launches": len(v)}
-    out = {"kernel": "renderKernel<false, false>", "dispatch": meta, "counters": med}
-    if "FETCH_SIZE" in med and "WRITE_SIZE" in med:
-        rd = med["FETCH_SIZE"]["median"] * 1024.0 * 2.0   # gfx950 correction, see docstring
-        wr = med["WRITE_SIZE"]["median"] * 1024.0
-        out["hbm_bytes_per_launch"] = {"read_corrected_x2": rd, "write": wr, "total": rd + wr,
-                                       "read_raw_counter": med["FETCH_SIZE"]["median"] * 1024.0}
-        tfile = os.path.join(dst, "hbm_traffic.json")
-        cur = json.load(open(tfile)) if os.path.exists(tfile) else {}
-        cur[scene] = {"bytes_per_launch": rd + wr, "from": tag + "_pmc.json"}
-        json.dump(cur, open(tfile, "w"), indent=1)
-    if "TCC_HIT_sum" in med and "TCC_MISS_sum" in med:
-        h, m = med["TCC_HIT_sum"]["median"], med["TCC_MISS_sum"]["median"]
-        out["l2_hit_rate"] = h / (h + m)
+    out = {"kernel": "renderKernel<false, false>", "scene": scene, "dispatch": meta, "counters": med}
+    m = lambda k: med[k]["median"] if k in med else None
+    inputs = {"from": "profiles/%s_pmc.json" % tag}
+    try:
+        inputs["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+    except Exception:
+        pass
+    if m("FETCH_SIZE") is not None and m("WRITE_SIZE") is not None:
+        rd = m("FETCH_SIZE") * 1024.0 * 2.0   # gfx950 correction, see docstring
+        wr = m("WRITE_SIZE") * 1024.0
+        out["hbm_bytes_per_launch"] = {"read_corrected_x2": rd, "write": wr, "total": rd + wr, "read_raw_counter": m("FETCH_SIZE") * 1024.0}
+        inputs["hbm_read_bytes"], inputs["hbm_write_bytes"] = rd, wr
+    if m("TCC_HIT_sum") is not None and m("TCC_MISS_sum") is not None:
+        out["l2_hit_rate"] = m("TCC_HIT_sum") / (m("TCC_HIT_sum") + m("TCC_MISS_sum"))
+        inputs["l2_requests"] = m("TCC_HIT_sum") + m("TCC_MISS_sum")
+    if m("TCC_REQ_sum") is not None:
+        inputs["l2_requests"] = m("TCC_REQ_sum")
+    if m("SQ_INSTS_VALU") is not None:
+        inputs["valu_insts"] = m("SQ_INSTS_VALU")
+    if m("SQ_THREAD_CYCLES_VALU") is not None:
+        inputs["thread_cycles_valu"] = m("SQ_THREAD_CYCLES_VALU")
+        if m("SQ_INSTS_VALU"):
+            out["lanes_active"] = m("SQ_THREAD_CYCLES_VALU") / (m("SQ_INSTS_VALU") * 64.0)
+    for k in ("SQ_INSTS_SALU", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_LDS", "SQ_WAVES"):
+        if m(k) is not None:
+            inputs[k.lower()] = m(k)
     json.dump(out, open(os.path.join(dst, tag + "_pmc.json"), "w"), indent=1)
+    rfile = os.path.join(dst, "roofline_inputs.json")
+    cur = json.load(open(rfile)) if os.path.exists(rfile) else {}
+    cur[scene] = inputs
+    json.dump(cur, open(rfile, "w"), indent=1)
     print(json.dumps(out, indent=1))
+    print(json.dumps(inputs, indent=1))
 
 
 if __name__ == "__main__":

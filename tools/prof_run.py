@@ -1,24 +1,31 @@
 #!/usr/bin/env python3
 """Run the CRT_PROF diagnostic build (libcrt_hip_prof.so): share of a wavefront's cycles in node steps / leaf steps / rest."""
-import sys, os, importlib
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
-import numpy as np
-import __graft_entry__ as e
-import torch
-pkg = e.load_package(); scenes = importlib.import_module(e.PKG_NAME + ".scenes")
-pkg.LIB_PATH = os.path.join(os.path.dirname(pkg.LIB_PATH), "libcrt_hip_prof.so")
-sc = scenes.heightfield(n_lights=1)
-r = pkg.Renderer(0); r.upload(sc["meshes"], sc["lights"], sc["materials"]); r.set_camera(sc["camera"]["position"], sc["camera"]["matrix"])
-W, H = 1920, 1080
-frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
-for mode in (3, 100):
-    r.change_shading_mode(mode)
-    for _ in range(4): r.render_frame_device(W, H, frame.data_ptr(), stats=True)
-    r.set_counting(True)
-    st = r.render_frame_device(W, H, frame.data_ptr(), stats=True)
-    c = r.read_counters().astype(np.float64)
-    r.set_counting(False)
-    tot, tn, tl, itn, itl, lan, lal = c[4:11]
-    print("mode %d: kernel %.3f ms (instrumented)  wave-cycles: node %.1f%%  leaf %.1f%%  other %.1f%%" % (mode, st["kernel_ms"], 100 * tn / tot, 100 * tl / tot, 100 * (tot - tn - tl) / tot))
-    print("   node phases: %d  (%.0f cycles each, %.1f lanes active)   leaf phases: %d (%.0f cycles each, %.1f lanes active)" % (itn, tn / itn, lan / itn, itl, tl / itl, lal / itl))
-    print("   node fetches %d  tri fetches %d -> per node phase %.1f lane-steps, per leaf phase %.1f tri tests" % (c[0], c[1], c[0] / itn, c[1] / itl))
+
+
+def main():
+    import sys, os, importlib
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+    import numpy as np
+    import __graft_entry__ as e
+    import torch
+    pkg = e.load_package(); scenes = importlib.import_module(e.PKG_NAME + ".scenes")
+    pkg.LIB_PATH = os.path.join(os.path.dirname(pkg.LIB_PATH), "libcrt_hip_prof.so")
+    sc = scenes.heightfield(n_lights=1)
+    r = pkg.Renderer(0); r.upload(sc["meshes"], sc["lights"], sc["materials"]); r.set_camera(sc["camera"]["position"], sc["camera"]["matrix"])
+    W, H = 1920, 1080
+    frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    for mode in (3, 100):
+        r.change_shading_mode(mode)
+        for _ in range(4): r.render_frame_device(W, H, frame.data_ptr(), stats=True)
+        r.set_counting(True)
+        st = r.render_frame_device(W, H, frame.data_ptr(), stats=True)
+        c = r.read_counters().astype(np.float64)
+        r.set_counting(False)
+        tot, tn, tl, itn, itl, lan, lal = c[4:11]
+        print("mode %d: kernel %.3f ms (instrumented)  wave-cycles: node %.1f%%  leaf %.1f%%  other %.1f%%" % (mode, st["kernel_ms"], 100 * tn / tot, 100 * tl / tot, 100 * (tot - tn - tl) / tot))
+        print("   node phases: %d  (%.0f cycles each, %.1f lanes active)   leaf phases: %d (%.0f cycles each, %.1f lanes active)" % (itn, tn / itn, lan / itn, itl, tl / itl, lal / itl))
+        print("   node fetches %d  tri fetches %d -> per node phase %.1f lane-steps, per leaf phase %.1f tri tests" % (c[0], c[1], c[0] / itn, c[1] / itl))
+
+
+if __name__ == "__main__":
+    main()
