@@ -91,7 +91,7 @@ def roofline_block(scene, launch_ms, kernel_ms_median, cnt, alg_bytes):
            "frac": None, "traffic": None,
            "peak_note": "1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
            "logical_bytes_per_launch": alg_bytes, "logical_GBs": alg_bytes / sec / 1e9,
-           "logical_note": "128 B x wide-node records fetched + 48 B x triangle records fetched + 4 B x pixels (SURVEY.md 8d): per-ray "
+           "logical_note": "64 B x quantised wide-node records fetched + 48 B x triangle records fetched + 4 B x pixels (SURVEY.md 8d): per-ray "
                            "logical fetches, served mostly by the scalar cache, L1, L2 and the Infinity Cache -- NOT an HBM rate, no frac",
            "nodes_fetched": cnt["nodes_visited"], "tris_fetched": cnt["tris_tested"]}
     src = os.path.join(ROOT, "profiles", "roofline_inputs.json")
@@ -183,7 +183,7 @@ def main():
     cnt = r.render_frame_device(W, H, frame0.data_ptr(), stats=True)
     r.set_counting(False)
     rays_per_frame = cnt["rays_primary"] + cnt["rays_shadow"]
-    alg_bytes_frame = 128 * cnt["nodes_visited"] + 48 * cnt["tris_tested"] + 4 * W * H  # 128-B wide nodes, 48-B triangles
+    alg_bytes_frame = 64 * cnt["nodes_visited"] + 48 * cnt["tris_tested"] + 4 * W * H  # 64-B quantised wide nodes, 48-B triangles
 
     def fence():
         if multi:

@@ -26,6 +26,8 @@ NODE_DTYPE = np.dtype([("lx0", "f4"), ("lx1", "f4"), ("ly0", "f4"), ("ly1", "f4"
                        ("left", "i4"), ("right", "i4"), ("pad0", "i4"), ("pad1", "i4")])
 NODE4_DTYPE = np.dtype([("minx", "f4", 4), ("maxx", "f4", 4), ("miny", "f4", 4), ("maxy", "f4", 4), ("minz", "f4", 4), ("maxz", "f4", 4),
                         ("ref", "i4", 4), ("pad", "i4", 4)])
+NODE4Q_DTYPE = np.dtype([("lo", "f4", 3), ("s", "f4", 3), ("qlo_x", "u4"), ("qhi_x", "u4"), ("qlo_y", "u4"), ("qhi_y", "u4"), ("qlo_z", "u4"), ("qhi_z", "u4"), ("ref", "i4", 4)])
+assert NODE4Q_DTYPE.itemsize == 64
 BVH_EMPTY = -0x80000000
 TRI_DTYPE = np.dtype([("v0", "f4", 3), ("inst", "u4"), ("e1", "f4", 3), ("prim", "u4"),
                       ("e2", "f4", 3), ("gid", "u4")])
@@ -37,7 +39,7 @@ ABI_SYMBOLS = [
     "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_set_option", "crt_debug_read_timeline", "crt_debug_read_counters", "crt_render_frame", "crt_render_frame_device",
     "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_render_frames_batch_device", "crt_render_tiles_batch_device",
     "crt_untile_device", "crt_untile_batch_device", "crt_set_stream", "crt_reset_stream",
-    "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_host_alloc", "crt_host_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_build_host4", "crt_build_stats",
+    "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_host_alloc", "crt_host_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_export4q", "crt_bvh_quantize4", "crt_bvh_build_host4", "crt_build_stats",
     "crt_scene_load", "crt_scene_save", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
     "crt_scene_add_material", "crt_scene_mesh_count", "crt_scene_mesh", "crt_scene_light_count", "crt_scene_light",
     "crt_scene_material_count", "crt_scene_material", "crt_scene_texture_count", "crt_scene_texture_color", "crt_scene_add_texture",
@@ -152,6 +154,8 @@ def lib():
         "crt_bvh_info4": (C.c_int, [vp, C.POINTER(u32), C.POINTER(u32)]),
         "crt_build_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "crt_bvh_export4": (C.c_int, [vp, vp]),
+        "crt_bvh_export4q": (C.c_int, [vp, vp]),
+        "crt_bvh_quantize4": (C.c_int, [vp, u32, vp]),
         "crt_bvh_build_host4": (C.c_int, [vp, u32, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]),
         "crt_scene_load": (C.c_int, [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]),
         "crt_scene_new": (C.c_int, [C.POINTER(vp)]),
@@ -465,6 +469,16 @@ def build_bvh4_host(meshes):
     return out, d4.value
 
 
+def quantize4(nodes4):
+    """crt_bvh_quantize4: wide nodes -> the 64-byte quantised nodes the kernels traverse (host only)"""
+    nodes4 = np.ascontiguousarray(nodes4, dtype=NODE4_DTYPE)
+    out = np.zeros(len(nodes4), dtype=NODE4Q_DTYPE)
+    rc = lib().crt_bvh_quantize4(nodes4.ctypes.data, len(nodes4), out.ctypes.data)
+    if rc != 0:
+        raise CrtError("crt_bvh_quantize4 failed rc=%d" % rc)
+    return out
+
+
 class Renderer:
     """crt_ctx handle: the DXRTRenderer surface over HIP. Raises CrtError when no MI355X / HIP device is usable."""
 
@@ -564,7 +578,7 @@ class Renderer:
         self._ok(lib().crt_set_option(self.h, name.encode(), int(value)), "crt_set_option")
 
     def read_counters(self):
-        buf = np.zeros(16, dtype=np.uint64)
+        buf = np.zeros(32, dtype=np.uint64)
         self._ok(lib().crt_debug_read_counters(self.h, buf.ctypes.data), "crt_debug_read_counters")
         return buf
 
@@ -608,6 +622,14 @@ class Renderer:
         nodes4 = np.zeros(a.value, dtype=NODE4_DTYPE)
         self._ok(lib().crt_bvh_export4(self.h, nodes4.ctypes.data), "crt_bvh_export4")
         return nodes4, b.value
+
+    def bvh_export4q(self):
+        """the quantised 64-byte nodes as they sit in HBM"""
+        a = C.c_uint32()
+        self._ok(lib().crt_bvh_info4(self.h, C.byref(a), None), "crt_bvh_info4")
+        q = np.zeros(a.value, dtype=NODE4Q_DTYPE)
+        self._ok(lib().crt_bvh_export4q(self.h, q.ctypes.data), "crt_bvh_export4q")
+        return q
 
     def pinned_frame(self, w, h):
         """RGBA8 frame buffer in page-locked host memory (crt_host_alloc), reused across calls of render_frame(pinned=True)."""

@@ -481,6 +481,7 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
 void collapseBvh4(Bvh& bvh)
 {
     bvh.nodes4.clear();
+    bvh.nodes4q.clear();
     bvh.depth4 = 0;
     if (bvh.nodes.empty()) return;
     struct Slot { int32_t ref; Box box; };
@@ -539,6 +540,65 @@ void collapseBvh4(Bvh& bvh)
         for (int i = n - 1; i >= 0; i--)
             if (sl[i].ref >= 0) work.push_back({ sl[i].ref, me, i, w.depth + 1 });
     }
+    bvh.nodes4q.resize(bvh.nodes4.size());
+    const int64_t nq = static_cast<int64_t>(bvh.nodes4.size());
+#pragma omp parallel for schedule(static) if (nq > 65536)
+    for (int64_t i = 0; i < nq; i++) quantizeNode4(bvh.nodes4[static_cast<size_t>(i)], bvh.nodes4q[static_cast<size_t>(i)]);
+}
+
+// Quantised nodes.  Per axis: lo / hi = the node's own extent over the children whose box is finite and ordered on that
+// axis; quantum s = (hi - lo) / 255 nudged up so that fma(255, s, lo) >= hi; a child's planes are the largest q with
+// fma(q, s, lo) <= min and the smallest q with fma(q, s, lo) >= max (the decode expression itself is what is checked, so
+// the decoded box contains the full-precision one whatever the rounding).  A child that is not finite on an axis spans
+// the whole node there (q = 0..255).  Extents beyond 3e38 are clamped (coordinates that large are not supported).
+// oracle/crt_oracle.c quantize_node4() is the same rule, expression for expression.
+namespace {
+inline float decodePlane(uint32_t q, float s, float lo) { return std::fmaf(static_cast<float>(q), s, lo); }
+}
+
+void quantizeNode4(const crt_bvh_node4& W, crt_bvh_node4q& Q)
+{
+    const float* mins[3] = { W.minx, W.miny, W.minz };
+    const float* maxs[3] = { W.maxx, W.maxy, W.maxz };
+    uint32_t qlo[3] = { 0, 0, 0 }, qhi[3] = { 0, 0, 0 };
+    for (int a = 0; a < 3; a++) {
+        float lo = std::numeric_limits<float>::infinity(), hi = -std::numeric_limits<float>::infinity();
+        bool valid[4];
+        for (int k = 0; k < 4; k++) {
+            const float mn = mins[a][k], mx = maxs[a][k];
+            valid[k] = W.ref[k] != CRT_BVH_EMPTY && std::isfinite(mn) && std::isfinite(mx) && mn <= mx;
+            if (valid[k]) {
+                lo = mn < lo ? mn : lo;
+                hi = mx > hi ? mx : hi;
+            }
+        }
+        if (!(lo <= hi)) lo = hi = 0.0f; // no finite child on this axis
+        float ext = hi - lo;
+        if (!(ext < 3.0e38f)) ext = 3.0e38f;
+        float s = (ext * (1.0f / 255.0f)) * 1.000001f;
+        if (!(s >= std::numeric_limits<float>::min())) s = std::numeric_limits<float>::min();
+        Q.lo[a] = lo;
+        Q.s[a] = s;
+        for (int k = 0; k < 4; k++) {
+            uint32_t l = 0, h = 255;
+            if (W.ref[k] == CRT_BVH_EMPTY) {
+                l = 255;
+                h = 0;
+            } else if (valid[k]) {
+                const float fl = (mins[a][k] - lo) / s, fh = (maxs[a][k] - lo) / s;
+                l = fl >= 255.0f ? 255u : (fl > 0.0f ? static_cast<uint32_t>(fl) : 0u);
+                while (l > 0 && decodePlane(l, s, lo) > mins[a][k]) l--;
+                h = fh >= 255.0f ? 255u : (fh > 0.0f ? static_cast<uint32_t>(fh) : 0u);
+                while (h < 255 && decodePlane(h, s, lo) < maxs[a][k]) h++;
+            }
+            qlo[a] |= l << (8 * k);
+            qhi[a] |= h << (8 * k);
+        }
+    }
+    Q.qlo_x = qlo[0]; Q.qhi_x = qhi[0];
+    Q.qlo_y = qlo[1]; Q.qhi_y = qhi[1];
+    Q.qlo_z = qlo[2]; Q.qhi_z = qhi[2];
+    for (int k = 0; k < 4; k++) Q.ref[k] = W.ref[k];
 }
 
 } // namespace crt

@@ -20,6 +20,7 @@ constexpr float kTravCost = 1.0f; // SAH cost of an inner-node visit, in triangl
 struct Bvh {
     std::vector<crt_bvh_node> nodes;   // binary tree, 64 B each, DFS pre-order, node 0 = root (builder output, host only)
     std::vector<crt_bvh_node4> nodes4; // wide tree collapsed from it, 128 B each, DFS pre-order: what is uploaded and traversed
+    std::vector<crt_bvh_node4q> nodes4q; // its 64-byte quantised form (quantizeBvh4): what is uploaded and traversed
     uint32_t depth4 = 0;               // levels of the wide tree
     std::vector<crt_bvh_tri> tris;     // 48 B each, leaf order
     std::vector<crt_bvh_shade> shade;  // 48 B each, leaf order
@@ -39,5 +40,7 @@ void flattenUvs(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<crt_
 void reorderUvs(const std::vector<crt_bvh_uv>& inUv, Bvh& bvh);
 // binary -> wide collapse (DESIGN.md "BVH4"); called by both builders
 void collapseBvh4(Bvh& bvh);
+// wide node -> 64-byte quantised node (DESIGN.md "Quantised nodes"); collapseBvh4 applies it to the whole tree
+void quantizeNode4(const crt_bvh_node4& W, crt_bvh_node4q& Q);
 
 } // namespace crt

@@ -197,10 +197,10 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.xcd_group = c->tuneXcdGroup;
     p.boost_units = c->tuneBoostUnits;
     p.debug_skip_units = c->debugSkipUnits;
-    // LDS part of the per-lane stack: 24 entries x 64 lanes x 4 B = 6 KB per wavefront -> 26 wavefronts per CU, the measured
-    // optimum (28 and 32 resident wavefronts are 5-10 % slower: L1 thrash); deeper entries (never seen on the test scenes,
-    // possible up to the builder's depth 32) spill to the arena
-    p.stack_entries = c->tuneStackEntries ? c->tuneStackEntries : 24u;
+    // LDS part of the per-lane stack: 16 entries x 64 lanes x 4 B = 4 KB per wavefront, so that LDS never limits the 7
+    // wavefronts per SIMD the kernel's register budget allows (12 .. 20 entries measured alike, 24 costs 4 %); no ray of the
+    // test scenes holds more than 15 entries, deeper ones (possible up to the builder's depth 32) spill to the arena
+    p.stack_entries = c->tuneStackEntries ? c->tuneStackEntries : 16u;
     p.n_batch = 1;
     p.units_per_frame = crt::renderUnitCount(p);
 }
@@ -210,7 +210,7 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
 {
     const bool counting = c->counting;
     HIP_TRY(c, hipSetDevice(c->device)); // the calling thread's current device may be another one (scratch hipMallocs below)
-    if (counting) HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 16 * sizeof(unsigned long long), c->stream));
+    if (counting) HIP_TRY(c, hipMemsetAsync(c->dCounters, 0, 32 * sizeof(unsigned long long), c->stream));
     if (c->wantTimeline && p.n_batch == 1) {
         const size_t words = 3 * (static_cast<size_t>(p.tiles_x + 4) * (p.tiles_y + 4) * 4 + 1024);
         if (c->timelineWords < words) {
@@ -389,7 +389,7 @@ int crt_create(crt_ctx** out, int device_id)
         (e = hipEventCreate(&c->evStart)) != hipSuccess || (e = hipEventCreate(&c->evStop)) != hipSuccess ||
         (e = createSideStream(c)) != hipSuccess ||
         (e = createRingEvents(c)) != hipSuccess ||
-        (e = hipMalloc(reinterpret_cast<void**>(&c->dCounters), 16 * sizeof(unsigned long long))) != hipSuccess) {
+        (e = hipMalloc(reinterpret_cast<void**>(&c->dCounters), 32 * sizeof(unsigned long long))) != hipSuccess) {
         const int rc = fail(nullptr, CRT_ENODEVICE, "HIP initialisation failed on device %d: %s", device_id, hipGetErrorString(e));
         crt_destroy(c);
         return rc;
@@ -491,7 +491,7 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     freeScene(c); // from here on a failure leaves NO scene (haveScene = false): never the new host tree over old device buffers
     std::swap(c->bvh, built);
     c->buildDeviceMs = deviceMs;
-    const size_t nb = sizeof(crt_bvh_node4) * c->bvh.nodes4.size(); // the wide tree is what the kernels traverse
+    const size_t nb = sizeof(crt_bvh_node4q) * c->bvh.nodes4q.size(); // the quantised wide tree is what the kernels traverse
     const size_t tb = sizeof(crt_bvh_tri) * c->bvh.tris.size();
     const size_t sb = sizeof(crt_bvh_shade) * c->bvh.shade.size();
     // +64 bytes of slack so that a speculative wide load of the last record stays inside the allocation
@@ -500,7 +500,7 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     HIP_TRY(c, hipMalloc(&c->dShade, sb + 64));
     HIP_TRY(c, hipMalloc(&c->dLights, sizeof(crt_light) * (n_lights + 1)));
     HIP_TRY(c, hipMalloc(&c->dMats, sizeof(crt_material) * (n_materials + 1)));
-    if (nb) HIP_TRY(c, hipMemcpy(c->dNodes, c->bvh.nodes4.data(), nb, hipMemcpyHostToDevice));
+    if (nb) HIP_TRY(c, hipMemcpy(c->dNodes, c->bvh.nodes4q.data(), nb, hipMemcpyHostToDevice));
     if (tb) HIP_TRY(c, hipMemcpy(c->dTris, c->bvh.tris.data(), tb, hipMemcpyHostToDevice));
     if (sb) HIP_TRY(c, hipMemcpy(c->dShade, c->bvh.shade.data(), sb, hipMemcpyHostToDevice));
     if (!c->bvh.uvs.empty()) {
@@ -676,12 +676,12 @@ int crt_debug_read_timeline(crt_ctx* c, unsigned long long* out, size_t max_word
     return CRT_OK;
 }
 
-int crt_debug_read_counters(crt_ctx* c, unsigned long long out[16])
+int crt_debug_read_counters(crt_ctx* c, unsigned long long out[32])
 {
     if (!c || !out) return CRT_EINVAL;
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    HIP_TRY(c, hipMemcpy(out, c->dCounters, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIP_TRY(c, hipMemcpy(out, c->dCounters, 32 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     return CRT_OK;
 }
 
@@ -875,6 +875,20 @@ int crt_bvh_export4(const crt_ctx* c, crt_bvh_node4* nodes4)
 {
     if (!c || !c->haveScene) return CRT_ESTATE;
     if (nodes4) crt::copyBytes(nodes4, c->bvh.nodes4.data(), sizeof(crt_bvh_node4) * c->bvh.nodes4.size());
+    return CRT_OK;
+}
+
+int crt_bvh_export4q(const crt_ctx* c, crt_bvh_node4q* nodes4q)
+{
+    if (!c || !c->haveScene) return CRT_ESTATE;
+    if (nodes4q) crt::copyBytes(nodes4q, c->bvh.nodes4q.data(), sizeof(crt_bvh_node4q) * c->bvh.nodes4q.size());
+    return CRT_OK;
+}
+
+int crt_bvh_quantize4(const crt_bvh_node4* nodes4, uint32_t n, crt_bvh_node4q* out)
+{
+    if ((!nodes4 || !out) && n) return fail(nullptr, CRT_EINVAL, "crt_bvh_quantize4: NULL argument");
+    for (uint32_t i = 0; i < n; i++) crt::quantizeNode4(nodes4[i], out[i]);
     return CRT_OK;
 }
 

@@ -13,7 +13,7 @@ constexpr int kStackEntries = 32;  // upper bound of the per-lane LDS traversal 
 
 struct RenderParams {
     // scene (HBM)
-    const void* nodes;   // crt_bvh_node4[n_nodes], 128 B (the wide tree)
+    const void* nodes;   // crt_bvh_node4q[n_nodes], 64 B (the quantised wide tree)
     const void* tris;    // crt_bvh_tri[n_tris], 48 B
     const void* shade;   // crt_bvh_shade[n_tris], 48 B
     const void* lights;  // crt_light[n_lights]

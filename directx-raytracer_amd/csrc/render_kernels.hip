@@ -41,11 +41,12 @@ constexpr uint32_t kBoostAfter = 300;
 #ifndef CRT_DIAG
 #define CRT_DIAG CRT_PROF
 #endif
-// Register budget: the primary/shadow-ray variant is asked for at least 6 wavefronts per SIMD (<= 80 VGPRs; it needs 78,
-// and the LDS stacks allow 26 wavefronts per CU).  7 (72 VGPRs, 36 B/lane spilled) measured 0.330 ms against 0.325,
-// 8 spills inside the loop (0.43).  The path-tracing variant keeps the compiler's choice: its live state does not fit.
+// Register budget: the primary/shadow-ray variant is asked for 7 wavefronts per SIMD (<= 72 VGPRs; one register spilled
+// outside the loops).  With the 64-byte quantised nodes a node in flight is 16 registers instead of 28, and with the LDS
+// stack at 16 entries (4 KB per wavefront) the CU holds those 28 wavefronts: 0.295 ms against 0.306 at 6 per SIMD;
+// 8 per SIMD (64 VGPRs) spills inside the loops (0.37).  The path-tracing variant keeps the compiler's choice.
 #ifndef CRT_WAVES_PER_EU
-#define CRT_WAVES_PER_EU 6
+#define CRT_WAVES_PER_EU 7
 #endif
 #define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(PATH ? 1 : CRT_WAVES_PER_EU, 8)))
 // scalar-cache fetches of records a whole wavefront shares (see loadNodeUniform): in the descent from the root, in any
@@ -133,36 +134,6 @@ __device__ __forceinline__ Ray makeRay(F3 o, F3 d)
     return r;
 }
 
-// slab test of one child box; returns hit and the entry distance
-__device__ __forceinline__ bool boxTest(float x0, float x1, float y0, float y1, float z0, float z1, const Ray& r,
-                                        float tmin, float tmax, float& tnear)
-{
-    const float ax = fmaf(x0, r.idir.x, r.noid.x), bx = fmaf(x1, r.idir.x, r.noid.x);
-    const float ay = fmaf(y0, r.idir.y, r.noid.y), by = fmaf(y1, r.idir.y, r.noid.y);
-    const float az = fmaf(z0, r.idir.z, r.noid.z), bz = fmaf(z1, r.idir.z, r.noid.z);
-    const float tn = fmaxf(fmaxf(fminf(ax, bx), fminf(ay, by)), fmaxf(fminf(az, bz), tmin));
-    const float tf = fminf(fminf(fmaxf(ax, bx), fmaxf(ay, by)), fminf(fmaxf(az, bz), tmax));
-    tnear = tn;
-    return tn <= tf;
-}
-
-// Slab test when the signs of the ray direction are known at compile time (OCT bit a set = direction component a is
-// negative): the near plane of each axis is then a fixed member of the (min, max) pair, so the six min/max of the
-// generic test disappear.  fma is monotonic in its first argument, so fma(near) <= fma(far) exactly as the generic
-// min()/max() would have chosen: results are bit-identical, only cheaper (12 instead of 24 min/max per node).
-template <int OCT>
-__device__ __forceinline__ bool boxTestOct(float x0, float x1, float y0, float y1, float z0, float z1, const Ray& r,
-                                           float tmin, float tmax, float& tnear)
-{
-    const float nx = (OCT & 1) ? x1 : x0, fx = (OCT & 1) ? x0 : x1;
-    const float ny = (OCT & 2) ? y1 : y0, fy = (OCT & 2) ? y0 : y1;
-    const float nz = (OCT & 4) ? z1 : z0, fz = (OCT & 4) ? z0 : z1;
-    const float tn = fmaxf(fmaxf(fmaf(nx, r.idir.x, r.noid.x), fmaf(ny, r.idir.y, r.noid.y)), fmaxf(fmaf(nz, r.idir.z, r.noid.z), tmin));
-    const float tf = fminf(fminf(fmaf(fx, r.idir.x, r.noid.x), fmaf(fy, r.idir.y, r.noid.y)), fminf(fmaf(fz, r.idir.z, r.noid.z), tmax));
-    tnear = tn;
-    return tn <= tf;
-}
-
 // Moeller-Trumbore, two sided; u = weight of v1, v = weight of v2.  NaN/inf from det == 0 fail the compares.
 __device__ __forceinline__ bool triTest(const Ray& r, const float4 a, const float4 b, const float4 c, float tmin,
                                         float& t, float& u, float& v)
@@ -191,6 +162,25 @@ struct Stack {
 #if CRT_PROF // diagnostic build (tools/prof_build.sh): where a wavefront's cycles go, never compiled into the product
     unsigned long long tNode = 0, tLeaf = 0;
     uint32_t itNode = 0, itLeaf = 0, lanesNode = 0, lanesLeaf = 0;
+    // divergent (per-lane fetched) steps: how many, lanes in them, runs of consecutive lanes on the same record, distinct records
+    uint32_t dvN = 0, dvNLanes = 0, dvNRuns = 0, dvNDistinct = 0, dvL = 0, dvLLanes = 0, dvLRuns = 0, dvLDistinct = 0, unN = 0, unL = 0;
+    __device__ __forceinline__ void divStats(int cur, uint32_t& steps, uint32_t& lanes, uint32_t& runs, uint32_t& distinct)
+    {
+        const unsigned long long act = __ballot(true);
+        const int prev = __shfl_up(cur, 1, 64);
+        const uint32_t lane = threadIdx.x & 63u;
+        const bool prevActive = lane > 0 && ((act >> (lane - 1)) & 1ull);
+        runs += __popcll(__ballot(!prevActive || prev != cur));
+        steps++;
+        lanes += __popcll(act);
+        unsigned long long rest = act;
+        while (rest) {
+            const int first = __ffsll(static_cast<long long>(rest)) - 1;
+            const int v = __shfl(cur, first, 64);
+            rest &= ~__ballot(cur == v);
+            distinct++;
+        }
+    }
 #endif
     __device__ __forceinline__ void push(int v)
     {
@@ -211,44 +201,63 @@ struct Hit {
     uint32_t gid;
 };
 
-// ---- wide (4-child) node step.  Node = 128 bytes = eight dwordx4 loads: minx[4] maxx[4] miny[4] maxy[4] minz[4] maxz[4]
-// ref[4] pad[4].  One memory round trip yields four slab tests, which halves the chain of dependent fetches a ray walks
-// (15.6 instead of 29.7 steps per ray on the 1M-triangle frame).  OCT < 8: direction signs known at compile time (near
-// plane of each axis = fixed member of the (min,max) pair; fma is monotonic, so this equals the generic min/max form
-// bit for bit); OCT = 8: generic.
-// An unused child slot carries ref CRT_BVH_EMPTY and an inverted box (+inf, -inf).  The octant-specialised slab test takes
-// the near plane from the (min, max) pair by the direction sign, so such a box yields t_near = +inf, t_far = -inf and never
-// hits: no emptiness test there.  The generic min/max form would turn it into all of space, so it still tests the ref.
+// ---- wide (4-child) node step.  Node = crt_bvh_node4q, 64 bytes = four dwordx4 loads:
+//   {lo.x lo.y lo.z s.x} {s.y s.z qlo_x qhi_x} {qlo_y qhi_y qlo_z qhi_z} {ref[4]}
+// The child planes are 8-bit offsets from the node's own minimum corner (byte k of a q word = child k): plane =
+// fma(q, s, lo).  The vector memory pipe -- per-lane fetch requests -- is what bounds this kernel, not vector arithmetic
+// (30 extra dependent VALU per step measured +0.5 %, one extra 4-byte touch per pushed child +29 %), so the record is
+// kept to four requests per lane instead of the seven of a full-precision node and decoded in registers.  The decode is
+// folded into the slab test: t(q) = fma(q, s * idir, fma(lo, idir, -o * idir)), monotonic in q with the sign of idir, so
+// for a known direction octant (OCT < 8) the near plane of each axis is a fixed member of the (qlo, qhi) pair and the
+// min/max pairs of the generic form (OCT = 8) disappear -- bit for bit the same values.
+// One memory round trip yields four slab tests (15.6 instead of 29.7 steps per ray on the 1M-triangle frame).
+// An unused child slot has ref CRT_BVH_EMPTY (tested explicitly).
 constexpr int kEmptyRef = INT_MIN;
 
+// one wide node in registers; fetched per lane (four dwordx4 vector loads) or, when the whole wavefront stands on the
+// same node, once through the scalar cache (constant address space + wave-uniform address = one s_load_dwordx16)
+struct NodeRegs {
+    float4 q0, q1, q2;
+    int4 refs;
+};
+constexpr size_t kNodeQuads = 4; // float4 per node record
+
+__device__ __forceinline__ float ubyteToFloat(uint32_t w, int k) { return static_cast<float>((w >> (8 * k)) & 0xFFu); } // v_cvt_f32_ubyteK
+
 template <int OCT>
-__device__ __forceinline__ void slab4(const float4& mnx, const float4& mxx, const float4& mny, const float4& mxy, const float4& mnz,
-                                      const float4& mxz, const Ray& r, float tmin, float tcull, float tn[4], bool hit[4])
+__device__ __forceinline__ void slab4(const NodeRegs& nd, const Ray& r, float tmin, float tcull, float tn[4], bool hit[4])
 {
-    const float ax[4] = { mnx.x, mnx.y, mnx.z, mnx.w }, bx[4] = { mxx.x, mxx.y, mxx.z, mxx.w };
-    const float ay[4] = { mny.x, mny.y, mny.z, mny.w }, by[4] = { mxy.x, mxy.y, mxy.z, mxy.w };
-    const float az[4] = { mnz.x, mnz.y, mnz.z, mnz.w }, bz[4] = { mxz.x, mxz.y, mxz.z, mxz.w };
+    const float ax = nd.q0.w * r.idir.x, ay = nd.q1.x * r.idir.y, az = nd.q1.y * r.idir.z;
+    const float bx = fmaf(nd.q0.x, r.idir.x, r.noid.x), by = fmaf(nd.q0.y, r.idir.y, r.noid.y), bz = fmaf(nd.q0.z, r.idir.z, r.noid.z);
+    const uint32_t lx = __float_as_uint(nd.q1.z), hx = __float_as_uint(nd.q1.w), ly = __float_as_uint(nd.q2.x), hy = __float_as_uint(nd.q2.y),
+                   lz = __float_as_uint(nd.q2.z), hz = __float_as_uint(nd.q2.w);
+    const int rf[4] = { nd.refs.x, nd.refs.y, nd.refs.z, nd.refs.w };
 #pragma unroll
     for (int k = 0; k < 4; k++) {
+        float t_n, t_f;
         if (OCT < 8) {
-            hit[k] = boxTestOct<OCT & 7>(ax[k], bx[k], ay[k], by[k], az[k], bz[k], r, tmin, tcull, tn[k]);
+            const float nx = ubyteToFloat((OCT & 1) ? hx : lx, k), fx = ubyteToFloat((OCT & 1) ? lx : hx, k);
+            const float ny = ubyteToFloat((OCT & 2) ? hy : ly, k), fy = ubyteToFloat((OCT & 2) ? ly : hy, k);
+            const float nz = ubyteToFloat((OCT & 4) ? hz : lz, k), fz = ubyteToFloat((OCT & 4) ? lz : hz, k);
+            t_n = fmaxf(fmaxf(fmaf(nx, ax, bx), fmaf(ny, ay, by)), fmaxf(fmaf(nz, az, bz), tmin));
+            t_f = fminf(fminf(fmaf(fx, ax, bx), fmaf(fy, ay, by)), fminf(fmaf(fz, az, bz), tcull));
         } else {
-            hit[k] = boxTest(ax[k], bx[k], ay[k], by[k], az[k], bz[k], r, tmin, tcull, tn[k]);
+            const float x0 = fmaf(ubyteToFloat(lx, k), ax, bx), x1 = fmaf(ubyteToFloat(hx, k), ax, bx);
+            const float y0 = fmaf(ubyteToFloat(ly, k), ay, by), y1 = fmaf(ubyteToFloat(hy, k), ay, by);
+            const float z0 = fmaf(ubyteToFloat(lz, k), az, bz), z1 = fmaf(ubyteToFloat(hz, k), az, bz);
+            t_n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+            t_f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tcull));
         }
+        tn[k] = t_n;
+        hit[k] = (t_n <= t_f) & (rf[k] != kEmptyRef);
     }
 }
 
-// one wide node in registers; fetched per lane (seven dwordx4 vector loads) or, when the whole wavefront stands on the
-// same node, once through the scalar cache (constant address space + wave-uniform address = s_load)
-struct NodeRegs {
-    float4 q0, q1, q2, q3, q4, q5;
-    int4 refs;
-};
 __device__ __forceinline__ NodeRegs loadNode(const float4* __restrict__ N)
 {
     NodeRegs nd;
-    nd.q0 = N[0]; nd.q1 = N[1]; nd.q2 = N[2]; nd.q3 = N[3]; nd.q4 = N[4]; nd.q5 = N[5];
-    nd.refs = *reinterpret_cast<const int4*>(N + 6);
+    nd.q0 = N[0]; nd.q1 = N[1]; nd.q2 = N[2];
+    nd.refs = *reinterpret_cast<const int4*>(N + 3);
     return nd;
 }
 __device__ __forceinline__ __attribute__((unused)) NodeRegs loadNodeUniform(const float4* N)
@@ -256,10 +265,9 @@ __device__ __forceinline__ __attribute__((unused)) NodeRegs loadNodeUniform(cons
     typedef float f4v __attribute__((ext_vector_type(4)));
     typedef const __attribute__((address_space(4))) f4v* ConstPtr;
     ConstPtr C = (ConstPtr)(reinterpret_cast<uintptr_t>(N));
-    const f4v a = C[0], b = C[1], c = C[2], d = C[3], e = C[4], f = C[5], g = C[6];
+    const f4v a = C[0], b = C[1], c = C[2], g = C[3];
     NodeRegs nd;
     nd.q0 = make_float4(a.x, a.y, a.z, a.w); nd.q1 = make_float4(b.x, b.y, b.z, b.w); nd.q2 = make_float4(c.x, c.y, c.z, c.w);
-    nd.q3 = make_float4(d.x, d.y, d.z, d.w); nd.q4 = make_float4(e.x, e.y, e.z, e.w); nd.q5 = make_float4(f.x, f.y, f.z, f.w);
     nd.refs = make_int4(__float_as_int(g.x), __float_as_int(g.y), __float_as_int(g.z), __float_as_int(g.w));
     return nd;
 }
@@ -286,17 +294,15 @@ template <bool COUNT, int BLOCK, int OCT>
 __device__ __forceinline__ void nodeStepClosestAt(const NodeRegs& nd, const Ray& r, float tmin, float tcull, Stack& stack,
                                                   int& cur, uint32_t& cntNodes)
 {
-    const float4 q0 = nd.q0, q1 = nd.q1, q2 = nd.q2, q3 = nd.q3, q4 = nd.q4, q5 = nd.q5;
     const int4 refs = nd.refs;
     if (COUNT) cntNodes++;
     float tn[4];
     bool hit[4];
-    slab4<OCT>(q0, q1, q2, q3, q4, q5, r, tmin, tcull, tn, hit);
-    const int rf[4] = { refs.x, refs.y, refs.z, refs.w };
+    slab4<OCT>(nd, r, tmin, tcull, tn, hit);
     uint32_t key[4];
 #pragma unroll
     for (int k = 0; k < 4; k++)
-        key[k] = (hit[k] & (OCT < 8 || rf[k] != kEmptyRef)) ? ((__float_as_uint(tn[k]) & 0x7FFFFFFCu) | static_cast<uint32_t>(k)) : 0xFFFFFFFFu;
+        key[k] = hit[k] ? ((__float_as_uint(tn[k]) & 0x7FFFFFFCu) | static_cast<uint32_t>(k)) : 0xFFFFFFFFu;
 #define CRT_CSWAP(a, b) { const uint32_t lo = min(key[a], key[b]), hi = max(key[a], key[b]); key[a] = lo; key[b] = hi; }
     CRT_CSWAP(0, 1) CRT_CSWAP(2, 3) CRT_CSWAP(0, 2) CRT_CSWAP(1, 3) CRT_CSWAP(1, 2)
 #undef CRT_CSWAP
@@ -315,14 +321,12 @@ template <bool COUNT, int BLOCK, int OCT>
 __device__ __forceinline__ void nodeStepAnyAt(const NodeRegs& nd, const Ray& r, float tmin, float tcull, Stack& stack,
                                               int& cur, uint32_t& cntNodes)
 {
-    const float4 q0 = nd.q0, q1 = nd.q1, q2 = nd.q2, q3 = nd.q3, q4 = nd.q4, q5 = nd.q5;
     const int4 refs = nd.refs;
     if (COUNT) cntNodes++;
     float tn[4];
     bool hit[4];
-    slab4<OCT>(q0, q1, q2, q3, q4, q5, r, tmin, tcull, tn, hit);
-    const bool h0 = hit[0] & (OCT < 8 || refs.x != kEmptyRef), h1 = hit[1] & (OCT < 8 || refs.y != kEmptyRef),
-               h2 = hit[2] & (OCT < 8 || refs.z != kEmptyRef), h3 = hit[3] & (OCT < 8 || refs.w != kEmptyRef);
+    slab4<OCT>(nd, r, tmin, tcull, tn, hit);
+    const bool h0 = hit[0], h1 = hit[1], h2 = hit[2], h3 = hit[3];
     if (!(h0 | h1 | h2 | h3)) {
         cur = stack.sp == 0 ? kDone : stack.pop();
     } else {
@@ -334,19 +338,6 @@ __device__ __forceinline__ void nodeStepAnyAt(const NodeRegs& nd, const Ray& r, 
     }
 }
 
-template <bool COUNT, int BLOCK, int OCT>
-__device__ __forceinline__ void nodeStepClosest(const float4* __restrict__ nodes, const Ray& r, float tmin, float tcull, Stack& stack,
-                                                int& cur, uint32_t& cntNodes)
-{
-    nodeStepClosestAt<COUNT, BLOCK, OCT>(loadNode(nodes + 8 * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);
-}
-template <bool COUNT, int BLOCK, int OCT>
-__device__ __forceinline__ void nodeStepAny(const float4* __restrict__ nodes, const Ray& r, float tmin, float tcull, Stack& stack,
-                                            int& cur, uint32_t& cntNodes)
-{
-    nodeStepAnyAt<COUNT, BLOCK, OCT>(loadNode(nodes + 8 * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);
-}
-
 // Uniform descent: the rays of an 8x8 packet start at the root and usually agree on the first few nodes.  While every
 // active lane stands on the SAME inner node its record is fetched once through the scalar cache (the node address is
 // wave-uniform, so the loads become s_load) instead of 64 identical per-lane vector fetches; each lane still runs its own
@@ -356,25 +347,40 @@ __device__ __forceinline__ void nodeStepAny(const float4* __restrict__ nodes, co
     for (;;) {                                                                                                                 \
         const int c0 = __builtin_amdgcn_readfirstlane(cur);                                                                    \
         if (c0 < 0 || __ballot(cur != c0) != 0ull) break;                                                                      \
-        STEP<COUNT, BLOCK, OCT>(loadNodeUniform(nodes + 8 * static_cast<size_t>(c0)), r, tmin, tcull, stack, cur, cntNodes);   \
+        STEP<COUNT, BLOCK, OCT>(loadNodeUniform(nodes + kNodeQuads * static_cast<size_t>(c0)), r, tmin, tcull, stack, cur, cntNodes);   \
     }
 #else
 #define CRT_UNIFORM_DESCENT(STEP)
 #endif
 // One node step of the lanes standing on inner nodes (called with exactly those lanes active): through the scalar cache
 // when they all stand on the same node, per lane otherwise.
+#if CRT_PROF
+#define CRT_DIV_STATS_NODE stack.divStats(cur, stack.dvN, stack.dvNLanes, stack.dvNRuns, stack.dvNDistinct);
+#define CRT_DIV_STATS_LEAF stack.divStats(cur, stack.dvL, stack.dvLLanes, stack.dvLRuns, stack.dvLDistinct);
+#else
+#define CRT_DIV_STATS_NODE
+#define CRT_DIV_STATS_LEAF
+#endif
+// One node step of the lanes standing on inner nodes (called with exactly those lanes active): through the scalar cache
+// when they all stand on the same node, per lane otherwise.
+// (Measured and rejected: fetching the DISTINCT nodes of a divergent step once each -- 6.6 distinct nodes among 50 wanting
+// lanes on the 1M-triangle frame -- by the first lanes of the wavefront and handing them out through LDS: a scalar loop
+// peels the distinct values, fetchers load and ds_write, every lane ds_reads its slot.  Bit-exact, a seventh of the
+// per-lane requests, and 0.49 ms instead of 0.31: the peeling loop and two LDS round trips per step cost far more than
+// the requests they save.)
 #if UNIFORM_STEP
 #define CRT_NODE_STEP(STEP)                                                                                                    \
     {                                                                                                                          \
         const int c0 = __builtin_amdgcn_readfirstlane(cur);                                                                    \
         if (__ballot(cur != c0) == 0ull) {                                                                                     \
-            STEP<COUNT, BLOCK, OCT>(loadNodeUniform(nodes + 8 * static_cast<size_t>(c0)), r, tmin, tcull, stack, cur, cntNodes); \
+            STEP<COUNT, BLOCK, OCT>(loadNodeUniform(nodes + kNodeQuads * static_cast<size_t>(c0)), r, tmin, tcull, stack, cur, cntNodes); \
         } else {                                                                                                               \
-            STEP<COUNT, BLOCK, OCT>(loadNode(nodes + 8 * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);     \
+            CRT_DIV_STATS_NODE                                                                                                 \
+            STEP<COUNT, BLOCK, OCT>(loadNode(nodes + kNodeQuads * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);     \
         }                                                                                                                      \
     }
 #else
-#define CRT_NODE_STEP(STEP) STEP<COUNT, BLOCK, OCT>(loadNode(nodes + 8 * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);
+#define CRT_NODE_STEP(STEP) STEP<COUNT, BLOCK, OCT>(loadNode(nodes + kNodeQuads * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);
 #endif
 
 // Wave-level scheduling shared by both traversals.  Every lane walks its own ray in its own fixed order (so results
@@ -440,6 +446,7 @@ __device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes
             } else
 #endif
 #if LEAF_PAIRS
+            CRT_DIV_STATS_LEAF
             // two triangles per memory round trip (same test order): the second record's loads overlap the first's
             for (uint32_t i = first; i < first + cnt; i += 2) {
                 const bool two = i + 1 < first + cnt;
@@ -963,6 +970,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
 #if CRT_PROF
     const unsigned long long tk0 = __builtin_amdgcn_s_memtime();
     unsigned long long pTNode = 0, pTLeaf = 0; uint32_t pItN = 0, pItL = 0, pLaN = 0, pLaL = 0;
+    uint32_t pDv[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
     uint32_t iters = 0; // traversal-loop iterations of this wavefront = its critical path, fed back as next frame's cost
     if (active) {
@@ -1010,6 +1018,8 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
 
 #if CRT_PROF
         pTNode = stack.tNode; pTLeaf = stack.tLeaf; pItN = stack.itNode; pItL = stack.itLeaf; pLaN = stack.lanesNode; pLaL = stack.lanesLeaf;
+        pDv[0] = stack.dvN; pDv[1] = stack.dvNLanes; pDv[2] = stack.dvNRuns; pDv[3] = stack.dvNDistinct;
+        pDv[4] = stack.dvL; pDv[5] = stack.dvLLanes; pDv[6] = stack.dvLRuns; pDv[7] = stack.dvLDistinct;
 #endif
         const uint32_t packed = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
         const size_t pix = static_cast<size_t>(py) * p.width + px;
@@ -1046,6 +1056,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
             atomicAdd(&p.counters[4], tk); atomicAdd(&p.counters[5], pTNode); atomicAdd(&p.counters[6], pTLeaf);
             atomicAdd(&p.counters[7], static_cast<unsigned long long>(pItN)); atomicAdd(&p.counters[8], static_cast<unsigned long long>(pItL));
             atomicAdd(&p.counters[9], static_cast<unsigned long long>(pLaN)); atomicAdd(&p.counters[10], static_cast<unsigned long long>(pLaL));
+            for (int i = 0; i < 8; i++) atomicAdd(&p.counters[11 + i], static_cast<unsigned long long>(pDv[i]));
         }
     }
 #endif

@@ -78,7 +78,7 @@ typedef struct crt_bvh_node {
     int32_t left, right; /* >= 0 inner node index; < 0 leaf: ~ref = (first_tri << 3) | count */
     int32_t pad0, pad1;
 } crt_bvh_node;
-/* 128-byte wide node the kernels traverse: up to 4 children, planes stored per axis across the children; collapsed from
+/* 128-byte wide node (full-precision child boxes; the builders' output, host side): up to 4 children, planes stored per axis across the children; collapsed from
  * the binary tree above. ref >= 0: wide node index; CRT_BVH_EMPTY: unused slot; other negatives: leaf (as above) */
 #define CRT_BVH_EMPTY ((int32_t)0x80000000)
 typedef struct crt_bvh_node4 {
@@ -86,6 +86,18 @@ typedef struct crt_bvh_node4 {
     int32_t ref[4];
     int32_t pad[4];
 } crt_bvh_node4;
+/* 64-byte quantised form of the wide node -- what sits in HBM and what the kernels traverse.  lo = minimum corner of the
+ * node's own box (union of its children), s = per-axis quantum; child k's box on axis a is
+ * [fma(qlo_a.byte[k], s_a, lo_a), fma(qhi_a.byte[k], s_a, lo_a)], rounded outwards (it always contains the full-precision
+ * box of crt_bvh_node4), so traversal results are unchanged and only the fetch counts differ by a percent or two.
+ * Derived from crt_bvh_node4 by a fixed rule (DESIGN.md "Quantised nodes"; csrc/bvh_build.cpp quantizeBvh4 and the
+ * oracle's restatement agree byte for byte).  Unused slots: ref = CRT_BVH_EMPTY, qlo = 255, qhi = 0. */
+typedef struct crt_bvh_node4q {
+    float lo[3];
+    float s[3];
+    uint32_t qlo_x, qhi_x, qlo_y, qhi_y, qlo_z, qhi_z; /* byte k (bits 8k..8k+7) = child k */
+    int32_t ref[4];
+} crt_bvh_node4q;
 typedef struct crt_bvh_tri { float v0[3]; uint32_t inst; float e1[3]; uint32_t prim; float e2[3]; uint32_t gid; } crt_bvh_tri;
 typedef struct crt_bvh_shade { float n0[3], n1[3], n2[3]; uint32_t material; uint32_t pad[2]; } crt_bvh_shade;
 typedef struct crt_bvh_uv { float uv0[2], uv1[2], uv2[2]; } crt_bvh_uv; /* 24 B, leaf order, only when some mesh has uvs */
@@ -180,7 +192,7 @@ int crt_untile_batch_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint3
  * change): "inner_min" 1..65 wave scheduling of the traversal loop, "xcd_group", "adaptive_order" (launch the most expensive 8x8
  * packets of the previous frame first: 0 never, 1 always, 2 = default: only for a frame issued on the same stream as the frame
  * before, where frames run one after another), "remeasure_every" (a moving camera re-measures packet costs every n-th use of a scratch slot; default 1), "boost_units",
- * "stack_entries" (0 = default 24; deeper entries spill to a
+ * "stack_entries" (0 = default 16; deeper entries spill to a
  * global arena). The diagnostic options "timeline", "debug_skip_units" and "debug_force_measure" (which do change what a frame
  * does) exist only in the diagnostic build of the library (tools/diag_build.sh); the product returns CRT_EINVAL for them. */
 int crt_set_option(crt_ctx* ctx, const char* name, int value);
@@ -188,9 +200,9 @@ int crt_set_option(crt_ctx* ctx, const char* name, int value);
 /* diagnostic build only (the product returns 0 words): with option "timeline" = 1 and counting enabled, a render records per workgroup {start, end} on the
  * 100 MHz s_memrealtime clock and (XCC id << 32 | tile_y << 16 | tile_x); this copies them out (3 words per workgroup) */
 int crt_debug_read_timeline(crt_ctx* ctx, unsigned long long* out, size_t max_words, size_t* n_words);
-/* raw device counters of the last counting render: [0] nodes [1] triangles [2] shadow rays [3] closest-hit rays; [4..10]
- * are filled only by the CRT_PROF diagnostic build of the kernels (tools/prof_build.sh) */
-int crt_debug_read_counters(crt_ctx* ctx, unsigned long long out[16]);
+/* raw device counters of the last counting render: [0] nodes [1] triangles [2] shadow rays [3] closest-hit rays; [4..31]
+ * are filled only by the CRT_PROF diagnostic build of the kernels (tools/prof_build.sh, meanings in tools/prof_run.py) */
+int crt_debug_read_counters(crt_ctx* ctx, unsigned long long out[32]);
 
 /* stream plumbing: run on an external hipStream_t (e.g. torch's current stream; NULL = HIP's default stream);
  * crt_reset_stream goes back to the context's private non-blocking stream */
@@ -209,12 +221,16 @@ int crt_build_stats(const crt_ctx* ctx, double* upload_ms, double* device_build_
 /* the wide tree as it sits in HBM: count/depth (any pointer may be NULL), then a copy of the nodes */
 int crt_bvh_info4(const crt_ctx* ctx, uint32_t* n_nodes4, uint32_t* depth4);
 int crt_bvh_export4(const crt_ctx* ctx, crt_bvh_node4* nodes4);
+/* the same nodes in the 64-byte quantised form the kernels fetch (count = n_nodes4) */
+int crt_bvh_export4q(const crt_ctx* ctx, crt_bvh_node4q* nodes4q);
 /* host-only BVH build, no device needed (used by crt_upload_scene; exposed for tests and tooling) */
 int crt_bvh_build_host(const crt_mesh_view* meshes, uint32_t n_meshes,
                        crt_bvh_node** nodes, uint32_t* n_nodes,
                        crt_bvh_tri** tris, crt_bvh_shade** shade, uint32_t* n_tris, uint32_t* max_depth);
 /* same build, additionally returning the collapsed wide tree (nodes4 freed with crt_free) */
 int crt_bvh_build_host4(const crt_mesh_view* meshes, uint32_t n_meshes, crt_bvh_node4** nodes4, uint32_t* n_nodes4, uint32_t* depth4);
+/* the quantisation rule alone: n wide nodes -> n quantised nodes (caller-provided output array) */
+int crt_bvh_quantize4(const crt_bvh_node4* nodes4, uint32_t n, crt_bvh_node4q* out);
 void crt_free(void* p);
 
 /* page-locked host memory for crt_render_frame's output buffers: the device-to-host copy of a frame then runs at PCIe speed

@@ -20,6 +20,7 @@
  */
 #include "crt_oracle.h"
 
+#include <float.h>
 #include <immintrin.h>
 #include <math.h>
 #include <stdlib.h>
@@ -109,7 +110,8 @@ uint8_t oracle_unorm8(float c)
 struct oracle_scene {
     oracle_node* nodes;   /* binary tree (the builder's output) */
     uint32_t n_nodes;
-    oracle_node4* nodes4; /* wide tree collapsed from it (what the render loop walks) */
+    oracle_node4* nodes4; /* wide tree collapsed from it */
+    oracle_node4q* nodes4q; /* its quantised form (what the render loop walks) */
     uint32_t n_nodes4;
     uint32_t depth4;
     int width;
@@ -315,9 +317,61 @@ static int32_t collapse_node(collapser* C, int32_t b, uint32_t depth)
     return (int32_t)me;
 }
 
+/* Quantised nodes: the rule of csrc/bvh_build.cpp quantizeNode4, restated.  Per axis: lo / hi over the children whose box
+ * is finite and ordered there; quantum s = (hi - lo) / 255 nudged up so that fma(255, s, lo) >= hi; child planes = largest
+ * q with fma(q, s, lo) <= min and smallest q with fma(q, s, lo) >= max (checked with the decode expression itself). */
+static inline float decode_plane(uint32_t q, float s, float lo) { return fmaf((float)q, s, lo); }
+
+static void quantize_node4(const oracle_node4* W, oracle_node4q* Q)
+{
+    const float* mins[3] = { W->minx, W->miny, W->minz };
+    const float* maxs[3] = { W->maxx, W->maxy, W->maxz };
+    uint32_t qlo[3] = { 0, 0, 0 }, qhi[3] = { 0, 0, 0 };
+    for (int a = 0; a < 3; a++) {
+        float lo = INFINITY, hi = -INFINITY;
+        int valid[4];
+        for (int k = 0; k < 4; k++) {
+            const float mn = mins[a][k], mx = maxs[a][k];
+            valid[k] = W->ref[k] != ORACLE_EMPTY && isfinite(mn) && isfinite(mx) && mn <= mx;
+            if (valid[k]) {
+                lo = mn < lo ? mn : lo;
+                hi = mx > hi ? mx : hi;
+            }
+        }
+        if (!(lo <= hi)) lo = hi = 0.0f;
+        float ext = hi - lo;
+        if (!(ext < 3.0e38f)) ext = 3.0e38f;
+        float sc = (ext * (1.0f / 255.0f)) * 1.000001f;
+        if (!(sc >= FLT_MIN)) sc = FLT_MIN;
+        Q->lo[a] = lo;
+        Q->s[a] = sc;
+        for (int k = 0; k < 4; k++) {
+            uint32_t l = 0, h = 255;
+            if (W->ref[k] == ORACLE_EMPTY) {
+                l = 255;
+                h = 0;
+            } else if (valid[k]) {
+                const float fl = (mins[a][k] - lo) / sc, fh = (maxs[a][k] - lo) / sc;
+                l = fl >= 255.0f ? 255u : (fl > 0.0f ? (uint32_t)fl : 0u);
+                while (l > 0 && decode_plane(l, sc, lo) > mins[a][k]) l--;
+                h = fh >= 255.0f ? 255u : (fh > 0.0f ? (uint32_t)fh : 0u);
+                while (h < 255 && decode_plane(h, sc, lo) < maxs[a][k]) h++;
+            }
+            qlo[a] |= l << (8 * k);
+            qhi[a] |= h << (8 * k);
+        }
+    }
+    Q->qlo_x = qlo[0]; Q->qhi_x = qhi[0];
+    Q->qlo_y = qlo[1]; Q->qhi_y = qhi[1];
+    Q->qlo_z = qlo[2]; Q->qhi_z = qhi[2];
+    for (int k = 0; k < 4; k++) Q->ref[k] = W->ref[k];
+}
+
 static void build_wide(oracle_scene* s)
 {
     free(s->nodes4);
+    free(s->nodes4q);
+    s->nodes4q = NULL;
     s->nodes4 = (oracle_node4*)calloc(s->n_nodes ? s->n_nodes : 1, sizeof(oracle_node4));
     s->n_nodes4 = 0;
     s->depth4 = 0;
@@ -326,6 +380,8 @@ static void build_wide(oracle_scene* s)
     collapse_node(&C, 0, 0);
     s->n_nodes4 = C.n_wide;
     s->depth4 = C.depth;
+    s->nodes4q = (oracle_node4q*)calloc(s->n_nodes4 ? s->n_nodes4 : 1, sizeof(oracle_node4q));
+    for (uint32_t i = 0; i < s->n_nodes4; i++) quantize_node4(&s->nodes4[i], &s->nodes4q[i]);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -583,7 +639,7 @@ oracle_scene* oracle_scene_create_ex(const oracle_mesh* meshes, uint32_t n_meshe
 void oracle_scene_destroy(oracle_scene* s)
 {
     if (!s) return;
-    free(s->nodes); free(s->nodes4); free(s->tris); free(s->shade); free(s->lights); free(s->mats); free(s->uvs);
+    free(s->nodes); free(s->nodes4); free(s->nodes4q); free(s->tris); free(s->shade); free(s->lights); free(s->mats); free(s->uvs);
     for (uint32_t i = 0; i < s->n_tex; i++) free((void*)s->tex[i].pixels);
     free(s->tex);
     free(s);
@@ -661,6 +717,7 @@ void oracle_texture_color(const oracle_texture* t, float u, float v, float out_r
 uint32_t oracle_scene_node_count(const oracle_scene* s) { return s->n_nodes; }
 uint32_t oracle_scene_node4_count(const oracle_scene* s) { return s->n_nodes4; }
 const oracle_node4* oracle_scene_nodes4(const oracle_scene* s) { return s->nodes4; }
+const oracle_node4q* oracle_scene_nodes4q(const oracle_scene* s) { return s->nodes4q; }
 uint32_t oracle_scene_depth4(const oracle_scene* s) { return s->depth4; }
 void oracle_scene_set_width(oracle_scene* s, int width) { s->width = width == 2 ? 2 : 4; }
 uint32_t oracle_scene_tri_count(const oracle_scene* s) { return s->n_tris; }
@@ -819,23 +876,28 @@ static int trace_any2(const oracle_scene* s, const ray* r, float tmin, float tma
 
 static inline uint32_t f2u(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
 
-/* the four slab tests of a wide node in one SSE pass: lane k = child k.  _mm_min_ps(a, b) is exactly minf_(a, b) = a < b ? a : b
- * (and max likewise), _mm_fmadd_ps is fmaf per lane: bit for bit box_test() applied to each child.  Returns the hit mask. */
-static inline int slab4(const oracle_node4* N, const ray* r, float tmin, float tcull, float tn_out[4])
+/* the four slab tests of a quantised wide node in one SSE pass: lane k = child k.  Planes are decoded inside the test:
+ * t(q) = fma(q, s * idir, fma(lo, idir, -o * idir)), the generic min/max form (the kernel's octant-specialised form picks
+ * the same members: t is monotonic in q).  _mm_min_ps(a, b) is exactly minf_(a, b) = a < b ? a : b (and max likewise),
+ * _mm_fmadd_ps is fmaf per lane.  Returns the hit mask. */
+static inline __m128 q_bytes(uint32_t w) { return _mm_cvtepi32_ps(_mm_cvtepu8_epi32(_mm_cvtsi32_si128((int)w))); }
+
+static inline int slab4(const oracle_node4q* N, const ray* r, float tmin, float tcull, float tn_out[4])
 {
-    const __m128 ix = _mm_set1_ps(r->idir.x), iy = _mm_set1_ps(r->idir.y), iz = _mm_set1_ps(r->idir.z);
-    const __m128 ox = _mm_set1_ps(r->noid.x), oy = _mm_set1_ps(r->noid.y), oz = _mm_set1_ps(r->noid.z);
-    const __m128 ax = _mm_fmadd_ps(_mm_loadu_ps(N->minx), ix, ox), bx = _mm_fmadd_ps(_mm_loadu_ps(N->maxx), ix, ox);
-    const __m128 ay = _mm_fmadd_ps(_mm_loadu_ps(N->miny), iy, oy), by = _mm_fmadd_ps(_mm_loadu_ps(N->maxy), iy, oy);
-    const __m128 az = _mm_fmadd_ps(_mm_loadu_ps(N->minz), iz, oz), bz = _mm_fmadd_ps(_mm_loadu_ps(N->maxz), iz, oz);
-    const __m128 tn = _mm_max_ps(_mm_max_ps(_mm_min_ps(ax, bx), _mm_min_ps(ay, by)), _mm_max_ps(_mm_min_ps(az, bz), _mm_set1_ps(tmin)));
-    const __m128 tf = _mm_min_ps(_mm_min_ps(_mm_max_ps(ax, bx), _mm_max_ps(ay, by)), _mm_min_ps(_mm_max_ps(az, bz), _mm_set1_ps(tcull)));
+    const __m128 ax = _mm_set1_ps(N->s[0] * r->idir.x), ay = _mm_set1_ps(N->s[1] * r->idir.y), az = _mm_set1_ps(N->s[2] * r->idir.z);
+    const __m128 bx = _mm_set1_ps(fmaf(N->lo[0], r->idir.x, r->noid.x)), by = _mm_set1_ps(fmaf(N->lo[1], r->idir.y, r->noid.y)),
+                 bz = _mm_set1_ps(fmaf(N->lo[2], r->idir.z, r->noid.z));
+    const __m128 x0 = _mm_fmadd_ps(q_bytes(N->qlo_x), ax, bx), x1 = _mm_fmadd_ps(q_bytes(N->qhi_x), ax, bx);
+    const __m128 y0 = _mm_fmadd_ps(q_bytes(N->qlo_y), ay, by), y1 = _mm_fmadd_ps(q_bytes(N->qhi_y), ay, by);
+    const __m128 z0 = _mm_fmadd_ps(q_bytes(N->qlo_z), az, bz), z1 = _mm_fmadd_ps(q_bytes(N->qhi_z), az, bz);
+    const __m128 tn = _mm_max_ps(_mm_max_ps(_mm_min_ps(x0, x1), _mm_min_ps(y0, y1)), _mm_max_ps(_mm_min_ps(z0, z1), _mm_set1_ps(tmin)));
+    const __m128 tf = _mm_min_ps(_mm_min_ps(_mm_max_ps(x0, x1), _mm_max_ps(y0, y1)), _mm_min_ps(_mm_max_ps(z0, z1), _mm_set1_ps(tcull)));
     _mm_storeu_ps(tn_out, tn);
     const __m128i empty = _mm_cmpeq_epi32(_mm_loadu_si128((const __m128i*)N->ref), _mm_set1_epi32((int)ORACLE_EMPTY));
     return _mm_movemask_ps(_mm_andnot_ps(_mm_castsi128_ps(empty), _mm_cmple_ps(tn, tf)));
 }
 
-static inline int wide_step(const oracle_node4* N, const ray* r, float tmin, float tcull, uint32_t key[4])
+static inline int wide_step(const oracle_node4q* N, const ray* r, float tmin, float tcull, uint32_t key[4])
 {
     float tn[4];
     const int mask = slab4(N, r, tmin, tcull, tn);
@@ -867,7 +929,7 @@ static void trace_closest4(const oracle_scene* s, const ray* r, float tmin, floa
     float tcull = tmax * CULL_PAD;
     for (;;) {
         if (cur >= 0) {
-            const oracle_node4* N = &s->nodes4[cur];
+            const oracle_node4q* N = &s->nodes4q[cur];
             uint32_t key[4];
             c->nodes++;
             int n_hit = wide_step(N, r, tmin, tcull, key);
@@ -907,7 +969,7 @@ static int trace_any4(const oracle_scene* s, const ray* r, float tmin, float tma
     const float tcull = tmax * CULL_PAD;
     for (;;) {
         if (cur >= 0) {
-            const oracle_node4* N = &s->nodes4[cur];
+            const oracle_node4q* N = &s->nodes4q[cur];
             c->nodes++;
             int first_hit = -1;
             int hits[4];

@@ -52,6 +52,16 @@ typedef struct oracle_node4 {
     int32_t pad[4];
 } oracle_node4;
 
+/* 64-byte quantised wide node: what the kernels fetch and what the wide walk below tests (DESIGN.md "Quantised nodes").
+ * Child k's box on axis a = [fma(qlo_a.byte[k], s[a], lo[a]), fma(qhi_a.byte[k], s[a], lo[a])], a superset of the
+ * full-precision box in oracle_node4. */
+typedef struct oracle_node4q {
+    float lo[3];
+    float s[3];
+    uint32_t qlo_x, qhi_x, qlo_y, qhi_y, qlo_z, qhi_z;
+    int32_t ref[4];
+} oracle_node4q;
+
 /* 48-byte leaf-ordered triangle: v0 and the two edges, ids in the w lanes. */
 typedef struct oracle_tri {
     float v0[3]; uint32_t inst; /* mesh ordinal      (DXR InstanceID)     */
@@ -116,6 +126,7 @@ void oracle_texture_color(const oracle_texture* t, float u, float v, float out_r
 uint32_t oracle_scene_node_count(const oracle_scene* s);
 uint32_t oracle_scene_node4_count(const oracle_scene* s);
 const oracle_node4* oracle_scene_nodes4(const oracle_scene* s);
+const oracle_node4q* oracle_scene_nodes4q(const oracle_scene* s); /* node4_count entries */
 uint32_t oracle_scene_depth4(const oracle_scene* s);
 /* traversal width used by oracle_render: 4 (default, the wide tree the kernels walk) or 2 (the binary tree it is collapsed from) */
 void oracle_scene_set_width(oracle_scene* s, int width);

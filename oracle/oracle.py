@@ -20,6 +20,8 @@ NODE_DTYPE = np.dtype([("lx0", "f4"), ("lx1", "f4"), ("ly0", "f4"), ("ly1", "f4"
                        ("left", "i4"), ("right", "i4"), ("pad0", "i4"), ("pad1", "i4")])
 NODE4_DTYPE = np.dtype([("minx", "f4", 4), ("maxx", "f4", 4), ("miny", "f4", 4), ("maxy", "f4", 4), ("minz", "f4", 4), ("maxz", "f4", 4),
                         ("ref", "i4", 4), ("pad", "i4", 4)])
+NODE4Q_DTYPE = np.dtype([("lo", "f4", 3), ("s", "f4", 3), ("qlo_x", "u4"), ("qhi_x", "u4"), ("qlo_y", "u4"), ("qhi_y", "u4"), ("qlo_z", "u4"), ("qhi_z", "u4"), ("ref", "i4", 4)])
+assert NODE4Q_DTYPE.itemsize == 64
 EMPTY = -0x80000000
 TRI_DTYPE = np.dtype([("v0", "f4", 3), ("inst", "u4"), ("e1", "f4", 3), ("prim", "u4"),
                       ("e2", "f4", 3), ("gid", "u4")])
@@ -100,7 +102,7 @@ def lib():
         for f in ("oracle_scene_node_count", "oracle_scene_tri_count", "oracle_scene_max_depth", "oracle_scene_node4_count", "oracle_scene_depth4"):
             getattr(L, f).restype = C.c_uint32
             getattr(L, f).argtypes = [C.c_void_p]
-        for f in ("oracle_scene_nodes", "oracle_scene_tris", "oracle_scene_shade", "oracle_scene_nodes4"):
+        for f in ("oracle_scene_nodes", "oracle_scene_tris", "oracle_scene_shade", "oracle_scene_nodes4", "oracle_scene_nodes4q"):
             getattr(L, f).restype = C.c_void_p
             getattr(L, f).argtypes = [C.c_void_p]
         L.oracle_render.restype = C.c_int
@@ -216,6 +218,10 @@ class OracleScene:
 
     def nodes4(self):
         return self._view("oracle_scene_nodes4", NODE4_DTYPE, self.n_nodes4)
+
+    def nodes4q(self):
+        """the 64-byte quantised nodes the wide walk (and the kernels) test"""
+        return self._view("oracle_scene_nodes4q", NODE4Q_DTYPE, self.n_nodes4)
 
     def set_width(self, width):
         """4 = wide tree (default, what the kernels walk), 2 = the binary tree it is collapsed from"""

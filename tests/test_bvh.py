@@ -86,12 +86,40 @@ def _check_wide(nodes, nodes4, depth4, tris):
     assert len(nodes4) <= len(nodes)
 
 
+def _check_quantised(nodes4, q):
+    """the 64-byte nodes the kernels fetch: decoded child boxes (the kernel's own decode expression, fma(q, s, lo) in float32)
+    contain the full-precision boxes and exceed them by less than two quanta; unused slots are marked; refs are copied"""
+    assert len(q) == len(nodes4)
+    if len(q) == 0:
+        return
+    EMPTY = -0x80000000
+    np.testing.assert_array_equal(q["ref"], nodes4["ref"])
+    used = nodes4["ref"] != EMPTY
+    for a, (qlo, qhi, mn, mx) in enumerate((("qlo_x", "qhi_x", "minx", "maxx"), ("qlo_y", "qhi_y", "miny", "maxy"), ("qlo_z", "qhi_z", "minz", "maxz"))):
+        lo, s = q["lo"][:, a].astype(np.float64), q["s"][:, a].astype(np.float64)
+        assert np.all(s > 0)
+        for k in range(4):
+            l = ((q[qlo] >> (8 * k)) & 0xFF).astype(np.float64)
+            h = ((q[qhi] >> (8 * k)) & 0xFF).astype(np.float64)
+            dec_lo = (l * s + lo).astype(np.float32)  # one rounding of the exact value = fmaf
+            dec_hi = (h * s + lo).astype(np.float32)
+            u = used[:, k]
+            fin = u & np.isfinite(nodes4[mn][:, k]) & np.isfinite(nodes4[mx][:, k])
+            assert np.all(dec_lo[fin] <= nodes4[mn][:, k][fin]) and np.all(dec_hi[fin] >= nodes4[mx][:, k][fin]), "quantised box must contain the exact one"
+            slack = 2.0 * s[fin] + 1e-6 * (np.abs(lo[fin]) + 255.0 * s[fin])
+            assert np.all(nodes4[mn][:, k][fin] - dec_lo[fin] <= slack) and np.all(dec_hi[fin] - nodes4[mx][:, k][fin] <= slack), "and be tight to two quanta"
+            assert np.all(l[~u] == 255) and np.all(h[~u] == 0)
+
+
 def _compare(pkg, oracle, meshes):
     nodes, tris, shade, md = pkg.build_bvh_host(meshes)
     O = oracle.OracleScene(meshes)
     nodes4, depth4 = pkg.build_bvh4_host(meshes)
     assert nodes4.tobytes() == O.nodes4().tobytes() and depth4 == O.depth4
     _check_wide(nodes, nodes4, depth4, tris)
+    q = pkg.quantize4(nodes4)  # the product's quantiser against the oracle's restatement of the rule, byte for byte
+    assert q.tobytes() == O.nodes4q().tobytes()
+    _check_quantised(nodes4, q)
     assert nodes.tobytes() == O.nodes().tobytes()
     assert tris.tobytes() == O.tris().tobytes()
     assert shade.tobytes() == O.shade().tobytes()

@@ -34,8 +34,9 @@ def _compare(pkg, oracle, renderer, sc, w, h, modes, exact_float=True, count=Tru
     # the product's own BVH is what sits in HBM; the oracle built its own independently: they must be identical
     nodes, tris, shade = renderer.bvh_export()
     assert nodes.tobytes() == O.nodes().tobytes() and tris.tobytes() == O.tris().tobytes() and shade.tobytes() == O.shade().tobytes()
-    nodes4, depth4 = renderer.bvh_export4()  # the wide tree actually traversed
+    nodes4, depth4 = renderer.bvh_export4()  # the wide tree, and its 64-byte quantised form: what is actually traversed
     assert nodes4.tobytes() == O.nodes4().tobytes() and depth4 == O.depth4
+    assert renderer.bvh_export4q().tobytes() == O.nodes4q().tobytes()
     for mode in modes:
         renderer.change_shading_mode(mode)
         ref = O.render(cam["position"], cam["matrix"], mode, w, h)

@@ -24,6 +24,11 @@ def main():
         tot, tn, tl, itn, itl, lan, lal = c[4:11]
         print("mode %d: kernel %.3f ms (instrumented)  wave-cycles: node %.1f%%  leaf %.1f%%  other %.1f%%" % (mode, st["kernel_ms"], 100 * tn / tot, 100 * tl / tot, 100 * (tot - tn - tl) / tot))
         print("   node phases: %d  (%.0f cycles each, %.1f lanes active)   leaf phases: %d (%.0f cycles each, %.1f lanes active)" % (itn, tn / itn, lan / itn, itl, tl / itl, lal / itl))
+        d = c[11:19]
+        if d[0] > 0:
+            print("   divergent node steps %d: %.1f lanes, %.1f runs of equal neighbours, %.1f distinct nodes each" % (d[0], d[1] / d[0], d[2] / d[0], d[3] / d[0]))
+        if d[4] > 0:
+            print("   divergent leaf steps %d: %.1f lanes, %.1f runs, %.1f distinct leaves each" % (d[4], d[5] / d[4], d[6] / d[4], d[7] / d[4]))
         print("   node fetches %d  tri fetches %d -> per node phase %.1f lane-steps, per leaf phase %.1f tri tests" % (c[0], c[1], c[0] / itn, c[1] / itl))
 
 
