@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_set_option", "crt_debug_read_timeline", "crt_debug_read_counters", "crt_render_frame", "crt_render_frame_device",
     "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_render_frames_batch_device", "crt_render_tiles_batch_device",
     "crt_untile_device", "crt_untile_batch_device", "crt_set_stream", "crt_reset_stream",
-    "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_host_alloc", "crt_host_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_export4q", "crt_bvh_quantize4", "crt_bvh_build_host4", "crt_build_stats",
+    "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_host_alloc", "crt_host_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_export4q", "crt_bvh_quantize4", "crt_comm_unique_id", "crt_comm_init", "crt_comm_destroy", "crt_comm_info", "crt_render_frame_distributed", "crt_bvh_build_host4", "crt_build_stats",
     "crt_scene_load", "crt_scene_save", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
     "crt_scene_add_material", "crt_scene_mesh_count", "crt_scene_mesh", "crt_scene_light_count", "crt_scene_light",
     "crt_scene_material_count", "crt_scene_material", "crt_scene_texture_count", "crt_scene_texture_color", "crt_scene_add_texture",
@@ -155,6 +155,11 @@ def lib():
         "crt_build_stats": (C.c_int, [vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
         "crt_bvh_export4": (C.c_int, [vp, vp]),
         "crt_bvh_export4q": (C.c_int, [vp, vp]),
+        "crt_comm_unique_id": (C.c_int, [vp]),
+        "crt_comm_init": (C.c_int, [vp, u32, u32, vp]),
+        "crt_comm_destroy": (C.c_int, [vp]),
+        "crt_comm_info": (C.c_int, [vp, C.POINTER(u32), C.POINTER(u32)]),
+        "crt_render_frame_distributed": (C.c_int, [vp, u32, u32, vp, vp, C.POINTER(FrameStats)]),
         "crt_bvh_quantize4": (C.c_int, [vp, u32, vp]),
         "crt_bvh_build_host4": (C.c_int, [vp, u32, C.POINTER(vp), C.POINTER(u32), C.POINTER(u32)]),
         "crt_scene_load": (C.c_int, [C.c_char_p, C.POINTER(vp), C.c_char_p, C.c_size_t]),
@@ -622,6 +627,31 @@ class Renderer:
         nodes4 = np.zeros(a.value, dtype=NODE4_DTYPE)
         self._ok(lib().crt_bvh_export4(self.h, nodes4.ctypes.data), "crt_bvh_export4")
         return nodes4, b.value
+
+    # native RCCL frame assembly (crt_comm_*): no torch involved
+    def comm_init(self, rank, n_ranks, unique_id=None):
+        """rank 0 may pass unique_id=None to create one; returns the 128-byte id (to be handed to the other ranks)"""
+        if unique_id is None:
+            buf = C.create_string_buffer(128)
+            rc = lib().crt_comm_unique_id(buf)
+            if rc != 0:
+                raise CrtError("crt_comm_unique_id failed rc=%d: %s" % (rc, lib().crt_last_error(None).decode()))
+            unique_id = buf.raw
+        self._ok(lib().crt_comm_init(self.h, rank, n_ranks, C.create_string_buffer(unique_id, 128)), "crt_comm_init")
+        return unique_id
+
+    def comm_destroy(self):
+        self._ok(lib().crt_comm_destroy(self.h), "crt_comm_destroy")
+
+    def render_frame_distributed(self, w, h, d_rgba8=None, host=False, stats=False):
+        out = np.zeros((h, w, 4), dtype=np.uint8) if host else None
+        st = FrameStats()
+        self._ok(lib().crt_render_frame_distributed(self.h, w, h, d_rgba8, out.ctypes.data if host else None, C.byref(st) if stats else None),
+                 "crt_render_frame_distributed")
+        res = {"stats": st.as_dict()} if stats else {}
+        if host:
+            res["rgba8"] = out
+        return res
 
     def bvh_export4q(self):
         """the quantised 64-byte nodes as they sit in HBM"""

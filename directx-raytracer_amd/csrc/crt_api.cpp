@@ -9,6 +9,9 @@
 #include "scene.h"
 
 #include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h> // types and prototypes only: the library is dlopen'ed by crt_comm_init (no link-time dependency)
+
+#include <dlfcn.h>
 
 #include <chrono>
 #include <cstdarg>
@@ -67,6 +70,7 @@ struct crt_ctx {
     uint32_t mode = 0;                 // R/DXRTRenderer.h:246 default shading mode
     bool counting = false;
     uint32_t pathSpp = 4, pathBounces = 3, pathSeed = 1234; // mode 200 (BASELINE.json configs[4]: 4 spp, 3 bounces)
+    uint32_t phongKsPermille = 0, phongExp = 32;            // mode 100: specular term, off by default
     uint32_t tuneInnerMin = 32;    // wave scheduling threshold of the traversal loop (render_kernels.hip)
     uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
     uint32_t tuneXcdGroup = 16;
@@ -106,6 +110,15 @@ struct crt_ctx {
     unsigned long long* dTimeline = nullptr; // diagnostic: 3 words per workgroup, counting variant only
     size_t timelineWords = 0;
     bool wantTimeline = false;
+
+    // native multi-GPU frame assembly (crt_comm_init): RCCL communicator + per-ring-slot staging / gathered / frame buffers
+    ncclComm_t comm = nullptr;
+    uint32_t commRank = 0, commRanks = 0;
+    void* dStage[kRing] = {};
+    void* dGather[kRing] = {};
+    void* dDistFrame[kRing] = {};
+    size_t stageBytes[kRing] = {}, gatherBytes[kRing] = {}, distFrameBytes[kRing] = {};
+    uint32_t distSerial = 0;
 
     // scratch frame buffers for the host-output path, grown on demand
     void* dFrame[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -180,6 +193,8 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.spp = c->pathSpp;
     p.max_bounces = c->pathBounces;
     p.seed = c->pathSeed;
+    p.phong_ks = static_cast<float>(c->phongKsPermille) / 1000.0f;
+    p.phong_exp = c->phongExp;
     p.width = w;
     p.height = h;
     p.tiles_x = (w + crt::kTile - 1) / crt::kTile;
@@ -407,6 +422,12 @@ void crt_destroy(crt_ctx* c)
     freeScene(c);
     for (int i = 0; i < 5; i++)
         if (c->dFrame[i]) (void)hipFree(c->dFrame[i]);
+    (void)crt_comm_destroy(c);
+    for (int i = 0; i < crt_ctx::kRing; i++) {
+        if (c->dStage[i]) (void)hipFree(c->dStage[i]);
+        if (c->dGather[i]) (void)hipFree(c->dGather[i]);
+        if (c->dDistFrame[i]) (void)hipFree(c->dDistFrame[i]);
+    }
     if (c->dCounters) (void)hipFree(c->dCounters);
     if (c->dTextures) (void)hipFree(c->dTextures);
     if (c->dTexels) (void)hipFree(c->dTexels);
@@ -612,6 +633,16 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
     }
     if (std::strcmp(name, "max_bounces") == 0 && value >= 0 && value <= 64) {
         c->pathBounces = static_cast<uint32_t>(value);
+        c->viewSerial++;
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "phong_ks") == 0 && value >= 0 && value <= 100000) {
+        c->phongKsPermille = static_cast<uint32_t>(value);
+        c->viewSerial++;
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "phong_exponent") == 0 && value >= 1 && value <= 65536) {
+        c->phongExp = static_cast<uint32_t>(value);
         c->viewSerial++;
         return CRT_OK;
     }
@@ -915,6 +946,147 @@ int crt_bvh_export(const crt_ctx* c, crt_bvh_node* nodes, crt_bvh_tri* tris, crt
     if (nodes) crt::copyBytes(nodes, c->bvh.nodes.data(), sizeof(crt_bvh_node) * c->bvh.nodes.size());
     if (tris) crt::copyBytes(tris, c->bvh.tris.data(), sizeof(crt_bvh_tri) * c->bvh.tris.size());
     if (shade) crt::copyBytes(shade, c->bvh.shade.data(), sizeof(crt_bvh_shade) * c->bvh.shade.size());
+    return CRT_OK;
+}
+
+
+// ------------------------------------------------------------------------------------------- native RCCL gather
+// One process per GPU; every rank renders its macro tiles into a tile-major staging buffer, ONE ncclAllGather per frame moves
+// them over xGMI (1 044 480 bytes per rank at 1080p / 8 GPUs, each rank's 7 inbound messages on 7 different links), the
+// untile kernel rebuilds the row-major frame: all on the context's stream, no host synchronisation in between.
+// RCCL is resolved at run time (dlopen): a process that already carries an RCCL (torch's librccl.so.1) shares that copy, a
+// C++-only process takes /opt/rocm/lib's; a process that never calls crt_comm_* needs none.
+namespace {
+struct RcclApi {
+    void* handle = nullptr;
+    ncclResult_t (*getUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*commInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*commDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*allGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*getErrorString)(ncclResult_t) = nullptr;
+    std::string error;
+};
+
+RcclApi& rccl()
+{
+    static RcclApi api;
+    if (api.handle || !api.error.empty()) return api;
+    for (const char* name : { "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" }) {
+        api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) {
+        api.error = std::string("cannot load RCCL (librccl.so.1): ") + dlerror();
+        return api;
+    }
+    api.getUniqueId = reinterpret_cast<decltype(api.getUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
+    api.commInitRank = reinterpret_cast<decltype(api.commInitRank)>(dlsym(api.handle, "ncclCommInitRank"));
+    api.commDestroy = reinterpret_cast<decltype(api.commDestroy)>(dlsym(api.handle, "ncclCommDestroy"));
+    api.allGather = reinterpret_cast<decltype(api.allGather)>(dlsym(api.handle, "ncclAllGather"));
+    api.getErrorString = reinterpret_cast<decltype(api.getErrorString)>(dlsym(api.handle, "ncclGetErrorString"));
+    if (!api.getUniqueId || !api.commInitRank || !api.commDestroy || !api.allGather || !api.getErrorString) {
+        api.error = "RCCL library lacks an expected entry point";
+        api.handle = nullptr;
+    }
+    return api;
+}
+
+int ensureBuffer(crt_ctx* c, void** ptr, size_t* have, size_t need)
+{
+    if (*have >= need) return CRT_OK;
+    HIP_TRY(c, hipDeviceSynchronize());
+    if (*ptr) (void)hipFree(*ptr);
+    *ptr = nullptr;
+    *have = 0;
+    HIP_TRY(c, hipMalloc(ptr, need));
+    *have = need;
+    return CRT_OK;
+}
+} // namespace
+
+int crt_comm_unique_id(void* id_out)
+{
+    if (!id_out) return fail(nullptr, CRT_EINVAL, "crt_comm_unique_id: NULL argument");
+    RcclApi& api = rccl();
+    if (!api.handle) return fail(nullptr, CRT_ENODEVICE, "%s", api.error.c_str());
+    ncclUniqueId id;
+    const ncclResult_t r = api.getUniqueId(&id);
+    if (r != ncclSuccess) return fail(nullptr, CRT_EHIP, "ncclGetUniqueId failed: %s", api.getErrorString(r));
+    static_assert(sizeof(id) == CRT_COMM_ID_BYTES, "crt_hip.h states the size of an RCCL unique id");
+    std::memcpy(id_out, &id, sizeof(id));
+    return CRT_OK;
+}
+
+int crt_comm_init(crt_ctx* c, uint32_t rank, uint32_t n_ranks, const void* unique_id)
+{
+    if (!c) return CRT_EINVAL;
+    if (!unique_id || n_ranks == 0 || rank >= n_ranks) return fail(c, CRT_EINVAL, "crt_comm_init: bad arguments (rank %u of %u)", rank, n_ranks);
+    if (c->comm) return fail(c, CRT_ESTATE, "crt_comm_init: the context already has a communicator (crt_comm_destroy first)");
+    RcclApi& api = rccl();
+    if (!api.handle) return fail(c, CRT_ENODEVICE, "%s", api.error.c_str());
+    HIP_TRY(c, hipSetDevice(c->device));
+    ncclUniqueId id;
+    std::memcpy(&id, unique_id, sizeof(id));
+    const ncclResult_t r = api.commInitRank(&c->comm, static_cast<int>(n_ranks), id, static_cast<int>(rank));
+    if (r != ncclSuccess) {
+        c->comm = nullptr;
+        return fail(c, CRT_EHIP, "ncclCommInitRank(rank %u of %u) failed: %s", rank, n_ranks, api.getErrorString(r));
+    }
+    c->commRank = rank;
+    c->commRanks = n_ranks;
+    return CRT_OK;
+}
+
+int crt_comm_destroy(crt_ctx* c)
+{
+    if (!c) return CRT_EINVAL;
+    if (!c->comm) return CRT_OK;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    const ncclResult_t r = rccl().commDestroy(c->comm);
+    c->comm = nullptr;
+    c->commRanks = 0;
+    return r == ncclSuccess ? CRT_OK : fail(c, CRT_EHIP, "ncclCommDestroy failed: %s", rccl().getErrorString(r));
+}
+
+int crt_comm_info(const crt_ctx* c, uint32_t* rank, uint32_t* n_ranks)
+{
+    if (!c) return CRT_EINVAL;
+    if (rank) *rank = c->commRank;
+    if (n_ranks) *n_ranks = c->commRanks; // 0: no communicator
+    return CRT_OK;
+}
+
+int crt_render_frame_distributed(crt_ctx* c, uint32_t w, uint32_t h, void* d_rgba8, uint8_t* host_rgba8, crt_frame_stats* stats)
+{
+    int rc = checkRenderable(c, w, h);
+    if (rc) return rc;
+    if (!c->comm) return fail(c, CRT_ESTATE, "crt_render_frame_distributed: no communicator (crt_comm_init first)");
+    const auto t0 = std::chrono::steady_clock::now();
+    HIP_TRY(c, hipSetDevice(c->device));
+    const uint32_t n = c->commRanks, slots = crt_tile_slots(w, h, n);
+    const size_t per = static_cast<size_t>(slots) * crt::kTile * crt::kTile * 4; // bytes each rank contributes
+    const uint32_t k = c->distSerial++ % crt_ctx::kRing;
+    if ((rc = ensureBuffer(c, &c->dStage[k], &c->stageBytes[k], per)) != CRT_OK) return rc;
+    if ((rc = ensureBuffer(c, &c->dGather[k], &c->gatherBytes[k], per * n)) != CRT_OK) return rc;
+    void* frame = d_rgba8;
+    if (!frame) {
+        if ((rc = ensureBuffer(c, &c->dDistFrame[k], &c->distFrameBytes[k], static_cast<size_t>(w) * h * 4)) != CRT_OK) return rc;
+        frame = c->dDistFrame[k];
+    }
+    crt_frame_stats local;
+    rc = crt_render_tiles_device(c, w, h, c->commRank, n, c->dStage[k], stats ? &local : nullptr);
+    if (rc) return rc;
+    const ncclResult_t r = rccl().allGather(c->dStage[k], c->dGather[k], per, ncclUint8, c->comm, c->stream);
+    if (r != ncclSuccess) return fail(c, CRT_EHIP, "ncclAllGather failed: %s", rccl().getErrorString(r));
+    rc = crt_untile_device(c, w, h, n, c->dGather[k], frame);
+    if (rc) return rc;
+    if (host_rgba8) HIP_TRY(c, hipMemcpyAsync(host_rgba8, frame, static_cast<size_t>(w) * h * 4, hipMemcpyDeviceToHost, c->stream));
+    if (stats || host_rgba8) HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (stats) {
+        *stats = local; // kernel_ms and the counters describe this rank's tile launch
+        stats->total_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
     return CRT_OK;
 }
 

@@ -1,74 +1,212 @@
 // crt_render -- headless driver: the MI355X replacement for DXRTApp's idle-tick loop (R/DXRTApp.cpp:92-120)
-// with the Qt window, input widgets and swap chain removed.  Loads a .crtscene / .obj, plays a scripted camera
-// path through the same Camera calls the reference's input handlers make (rotate / zoom / moveForward /
-// moveRight; R/DXRTApp.cpp:36-47,92-107), renders N frames, prints ms/frame and Mray/s (the reference shows an
-// FPS label, R/DXRTApp.cpp:82-90) and optionally writes PPM images.
+// with the Qt window, input widgets and swap chain removed.  Loads a .crtscene / .obj / .crtbin, plays a scripted
+// camera path through the same Camera calls the reference's input handlers make -- W/S -> moveForward, A/D ->
+// moveRight (R/DXRTApp.cpp:91-107), mouse -> rotate (R/DXRTViewportWidget.cpp:50-72), wheel -> zoom (:74-78) -- and
+// the shading-mode switch of its combo box (R/DXRTMainWindow.cpp:114-121), renders N frames, prints ms/frame and
+// Mray/s (the reference shows an FPS label, R/DXRTApp.cpp:82-90) and optionally writes PPM images.
+//
+// --ranks N: one process per GPU, launched from here, no Python: the parent (which never touches the GPU) starts N
+// copies of itself with --rank r; rank r renders on device r, the frame is tile-partitioned and assembled with one
+// RCCL all-gather per frame (crt_render_frame_distributed); rank 0 prints and writes the images.
 #include "renderer.h"
+
+#include <sys/wait.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <exception>
+#include <fstream>
+#include <map>
+#include <sstream>
 #include <string>
+#include <vector>
 
 static void usage()
 {
     std::fprintf(stderr,
-                 "usage: crt_render <scene.crtscene|scene.obj> [--mode M] [--size WxH] [--frames N] [--device D]\n"
-                 "                  [--orbit DEG_PER_FRAME] [--forward UNITS_PER_FRAME] [--out prefix] [--count]\n");
+                 "usage: crt_render <scene.crtscene|scene.obj|scene.crtbin> [--mode M] [--size WxH] [--frames N] [--device D]\n"
+                 "   per-frame camera script (applied before every frame but the first):\n"
+                 "       [--orbit DEG] [--pitch DEG] [--forward UNITS] [--right UNITS] [--zoom AMOUNT]\n"
+                 "       [--path FILE]   one line per frame, commands separated by ';':\n"
+                 "                       rotate YAW PITCH | forward D | right D | zoom A | pan DEG | tilt DEG | roll DEG | mode M\n"
+                 "   [--mode-at FRAME:MODE]...  switch the shading mode from that frame on\n"
+                 "   [--spp N] [--bounces N] [--seed N]   mode 200 (path tracing)\n"
+                 "   [--phong KS_PERMILLE:EXPONENT]       mode 100 specular term\n"
+                 "   [--out prefix] [--count]\n"
+                 "   [--ranks N [--device-base D] [--id-file PATH]]   N processes / GPUs, RCCL gather per frame\n");
 }
+
+namespace {
+struct Args {
+    std::string scene, out, pathFile, idFile;
+    uint32_t mode = 0, w = 1920, h = 1080;
+    int frames = 1, device = 0, deviceBase = 0, ranks = 0, rank = -1;
+    int spp = -1, bounces = -1, seed = -1, phongKs = -1, phongExp = -1;
+    float orbit = 0.f, pitch = 0.f, forward = 0.f, right = 0.f, zoom = 0.f;
+    bool count = false;
+    std::map<int, uint32_t> modeAt;
+};
+
+// one line of a --path file applied to the camera / renderer: the calls the reference's handlers make
+void applyScriptLine(const std::string& line, crt::Renderer& renderer)
+{
+    std::stringstream cmds(line);
+    std::string cmd;
+    while (std::getline(cmds, cmd, ';')) {
+        std::stringstream ss(cmd);
+        std::string op;
+        if (!(ss >> op) || op[0] == '#') continue;
+        crt::Camera& cam = renderer.getScene().getCamera();
+        float a = 0.f, b = 0.f;
+        if (op == "rotate" && (ss >> a >> b)) cam.rotate(a, b);
+        else if (op == "forward" && (ss >> a)) cam.moveForward(-a); // W: moveForward(-speed * dt), R/DXRTApp.cpp:96-97
+        else if (op == "right" && (ss >> a)) cam.moveRight(a);      // D: moveRight(+speed * dt), R/DXRTApp.cpp:105-106
+        else if (op == "zoom" && (ss >> a)) cam.zoom(a);
+        else if (op == "pan" && (ss >> a)) cam.pan(a);
+        else if (op == "tilt" && (ss >> a)) cam.tilt(a);
+        else if (op == "roll" && (ss >> a)) cam.roll(a);
+        else if (op == "mode" && (ss >> a)) renderer.changeShadingMode(static_cast<uint32_t>(a));
+        else throw std::runtime_error("camera path: cannot parse '" + cmd + "'");
+    }
+}
+
+int runRank(const Args& a)
+{
+    crt::Renderer renderer;
+    const int device = a.ranks > 0 ? a.deviceBase + a.rank : a.device;
+    renderer.prepareForRendering(a.scene, device);
+    renderer.setFrameSize(a.w, a.h);
+    renderer.changeShadingMode(a.mode);
+    renderer.setCounting(a.count);
+    if (a.spp >= 0) renderer.setOption("spp", a.spp);
+    if (a.bounces >= 0) renderer.setOption("max_bounces", a.bounces);
+    if (a.seed >= 0) renderer.setOption("seed", a.seed);
+    if (a.phongKs >= 0) renderer.setOption("phong_ks", a.phongKs);
+    if (a.phongExp >= 0) renderer.setOption("phong_exponent", a.phongExp);
+    if (a.ranks > 0) renderer.joinRanks(static_cast<uint32_t>(a.rank), static_cast<uint32_t>(a.ranks), a.idFile);
+    const bool talk = a.ranks <= 0 || a.rank == 0;
+    std::vector<std::string> script;
+    if (!a.pathFile.empty()) {
+        std::ifstream f(a.pathFile);
+        if (!f) throw std::runtime_error("cannot open camera path '" + a.pathFile + "'");
+        for (std::string line; std::getline(f, line);) script.push_back(line);
+    }
+    double sumMs = 0.0;
+    uint32_t mode = a.mode;
+    for (int f = 0; f < a.frames; f++) {
+        if (f > 0) { // scripted input, same calls as the reference's handlers
+            crt::Camera& cam = renderer.getScene().getCamera();
+            if (a.orbit != 0.f || a.pitch != 0.f) cam.rotate(a.orbit, a.pitch);
+            if (a.forward != 0.f) cam.moveForward(-a.forward);
+            if (a.right != 0.f) cam.moveRight(a.right);
+            if (a.zoom != 0.f) cam.zoom(a.zoom);
+        }
+        if (static_cast<size_t>(f) < script.size()) applyScriptLine(script[static_cast<size_t>(f)], renderer);
+        const auto sw = a.modeAt.find(f);
+        if (sw != a.modeAt.end()) {
+            mode = sw->second;
+            renderer.changeShadingMode(mode);
+        }
+        renderer.renderFrame();
+        const crt_frame_stats& st = renderer.getLastFrameStats();
+        sumMs += st.kernel_ms;
+        if (!talk) continue;
+        const double rays = static_cast<double>(st.rays_primary + st.rays_shadow);
+        std::printf("frame %d: kernel %.3f ms, call %.3f ms, %.1f Mray/s", f, st.kernel_ms, st.total_ms, rays / st.kernel_ms * 1e-3);
+        if (a.ranks > 0) std::printf(" (rank 0's tile share of %d ranks)", a.ranks);
+        if (a.count) std::printf(", nodes %llu, tris %llu, shadow rays %llu", (unsigned long long)st.nodes_visited,
+                                 (unsigned long long)st.tris_tested, (unsigned long long)st.rays_shadow);
+        std::printf("\n");
+        if (!a.out.empty()) renderer.writePPM(a.out + "_" + std::to_string(f) + ".ppm");
+    }
+    if (talk) std::printf("average kernel %.3f ms/frame over %d frames (%ux%u, mode %u)\n", sumMs / a.frames, a.frames, a.w, a.h, a.mode);
+    renderer.stopRendering();
+    return 0;
+}
+
+// parent of an N-rank run: starts the rank processes BEFORE anything here touches the GPU, waits for all of them
+int launchRanks(const Args& a, int argc, char** argv)
+{
+    std::string idFile = a.idFile;
+    if (idFile.empty()) idFile = "/tmp/crt_render_comm_" + std::to_string(static_cast<long>(getpid())) + ".id";
+    std::remove(idFile.c_str());
+    std::vector<pid_t> kids;
+    for (int r = 0; r < a.ranks; r++) {
+        const pid_t pid = fork();
+        if (pid < 0) { std::perror("fork"); return 1; }
+        if (pid == 0) {
+            std::vector<std::string> args(argv, argv + argc);
+            args.push_back("--rank");
+            args.push_back(std::to_string(r));
+            args.push_back("--id-file");
+            args.push_back(idFile);
+            std::vector<char*> cargs;
+            for (std::string& s : args) cargs.push_back(s.data());
+            cargs.push_back(nullptr);
+            execv("/proc/self/exe", cargs.data());
+            std::perror("execv");
+            _exit(127);
+        }
+        kids.push_back(pid);
+    }
+    int rc = 0;
+    for (pid_t pid : kids) {
+        int status = 0;
+        if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) rc = 1;
+    }
+    std::remove(idFile.c_str());
+    return rc;
+}
+} // namespace
 
 int main(int argc, char** argv)
 {
     if (argc < 2) { usage(); return 2; }
-    std::string scenePath = argv[1], out;
-    uint32_t mode = 0, w = 1920, h = 1080;
-    int frames = 1, device = 0;
-    float orbit = 0.f, forward = 0.f;
-    bool count = false;
+    Args a;
+    a.scene = argv[1];
     for (int i = 2; i < argc; i++) {
-        const std::string a = argv[i];
+        const std::string s = argv[i];
         auto next = [&](const char* name) -> const char* {
             if (i + 1 >= argc) { std::fprintf(stderr, "%s needs a value\n", name); std::exit(2); }
             return argv[++i];
         };
-        if (a == "--mode") mode = static_cast<uint32_t>(std::atoi(next("--mode")));
-        else if (a == "--size") { if (std::sscanf(next("--size"), "%ux%u", &w, &h) != 2) { usage(); return 2; } }
-        else if (a == "--frames") frames = std::atoi(next("--frames"));
-        else if (a == "--device") device = std::atoi(next("--device"));
-        else if (a == "--orbit") orbit = static_cast<float>(std::atof(next("--orbit")));
-        else if (a == "--forward") forward = static_cast<float>(std::atof(next("--forward")));
-        else if (a == "--out") out = next("--out");
-        else if (a == "--count") count = true;
+        if (s == "--mode") a.mode = static_cast<uint32_t>(std::atoi(next("--mode")));
+        else if (s == "--size") { if (std::sscanf(next("--size"), "%ux%u", &a.w, &a.h) != 2) { usage(); return 2; } }
+        else if (s == "--frames") a.frames = std::atoi(next("--frames"));
+        else if (s == "--device") a.device = std::atoi(next("--device"));
+        else if (s == "--orbit") a.orbit = static_cast<float>(std::atof(next("--orbit")));
+        else if (s == "--pitch") a.pitch = static_cast<float>(std::atof(next("--pitch")));
+        else if (s == "--forward") a.forward = static_cast<float>(std::atof(next("--forward")));
+        else if (s == "--right") a.right = static_cast<float>(std::atof(next("--right")));
+        else if (s == "--zoom") a.zoom = static_cast<float>(std::atof(next("--zoom")));
+        else if (s == "--path") a.pathFile = next("--path");
+        else if (s == "--mode-at") {
+            int f = 0;
+            unsigned m = 0;
+            if (std::sscanf(next("--mode-at"), "%d:%u", &f, &m) != 2 || f < 0) { usage(); return 2; }
+            a.modeAt[f] = m;
+        }
+        else if (s == "--spp") a.spp = std::atoi(next("--spp"));
+        else if (s == "--bounces") a.bounces = std::atoi(next("--bounces"));
+        else if (s == "--seed") a.seed = std::atoi(next("--seed"));
+        else if (s == "--phong") { if (std::sscanf(next("--phong"), "%d:%d", &a.phongKs, &a.phongExp) != 2) { usage(); return 2; } }
+        else if (s == "--out") a.out = next("--out");
+        else if (s == "--count") a.count = true;
+        else if (s == "--ranks") a.ranks = std::atoi(next("--ranks"));
+        else if (s == "--rank") a.rank = std::atoi(next("--rank"));
+        else if (s == "--device-base") a.deviceBase = std::atoi(next("--device-base"));
+        else if (s == "--id-file") a.idFile = next("--id-file");
         else { usage(); return 2; }
     }
+    if (a.frames < 1 || a.ranks < 0 || a.ranks > 64) { usage(); return 2; }
     try {
-        crt::Renderer renderer;
-        renderer.prepareForRendering(scenePath, device);
-        renderer.setFrameSize(w, h);
-        renderer.changeShadingMode(mode);
-        renderer.setCounting(count);
-        double sumMs = 0.0;
-        for (int f = 0; f < frames; f++) {
-            if (f > 0) { // scripted input, same calls as the reference's handlers
-                if (orbit != 0.f) renderer.getScene().getCamera().rotate(orbit, 0.f);
-                if (forward != 0.f) renderer.getScene().getCamera().moveForward(-forward);
-            }
-            renderer.renderFrame();
-            const crt_frame_stats& st = renderer.getLastFrameStats();
-            sumMs += st.kernel_ms;
-            const double rays = static_cast<double>(st.rays_primary + st.rays_shadow);
-            std::printf("frame %d: kernel %.3f ms, call %.3f ms, %.1f Mray/s", f, st.kernel_ms, st.total_ms, rays / st.kernel_ms * 1e-3);
-            if (count) std::printf(", nodes %llu, tris %llu, shadow rays %llu", (unsigned long long)st.nodes_visited,
-                                   (unsigned long long)st.tris_tested, (unsigned long long)st.rays_shadow);
-            std::printf("\n");
-            if (!out.empty()) renderer.writePPM(out + "_" + std::to_string(f) + ".ppm");
-        }
-        std::printf("average kernel %.3f ms/frame over %d frames (%ux%u, mode %u)\n", sumMs / frames, frames, w, h, mode);
-        renderer.stopRendering();
+        if (a.ranks > 0 && a.rank < 0) return launchRanks(a, argc, argv);
+        if (a.ranks > 0 && (a.rank >= a.ranks || a.idFile.empty())) { usage(); return 2; }
+        return runRank(a);
     } catch (const std::exception& ex) {
         std::fprintf(stderr, "crt_render: %s\n", ex.what());
         return 1;
     }
-    return 0;
 }

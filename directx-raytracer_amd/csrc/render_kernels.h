@@ -29,6 +29,8 @@ struct RenderParams {
     float miss[3];
     uint32_t mode;
     uint32_t spp, max_bounces, seed; // mode 200 (path tracing)
+    float phong_ks;                  // mode 100: specular coefficient (0 = plain Lambert), options "phong_ks" / "phong_exponent"
+    uint32_t phong_exp;
     uint32_t width, height;
     // tiling
     uint32_t tiles_x, tiles_y;   // ceil(width/16), ceil(height/16)

@@ -770,9 +770,22 @@ __device__ __forceinline__ F3 biasPoint(F3 P, F3 N, float bias)
     return f3(fmaf(N.x, bias, P.x), fmaf(N.y, bias, P.y), fmaf(N.z, bias, P.z));
 }
 
-// direct light at Po: one any-hit shadow ray per light with a positive cosine (oracle: direct_light)
-template <bool COUNT, int BLOCK>
-__device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* nodes, const float4* tris, F3 Po, F3 N, F3 albedo,
+// x^n by square and multiply in the oracle's order (pow_uint)
+__device__ __forceinline__ float powUint(float x, uint32_t n)
+{
+    float result = 1.0f, base = x;
+    while (n) {
+        if (n & 1u) result *= base;
+        base *= base;
+        n >>= 1;
+    }
+    return result;
+}
+
+// direct light at Po: one any-hit shadow ray per light with a positive cosine (oracle: direct_light).  PHONG (mode 100
+// only): plus the specular term ks * I / (4 pi r^2) * max(0, R . view)^n, R = the light direction mirrored about N.
+template <bool COUNT, int BLOCK, bool PHONG>
+__device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* nodes, const float4* tris, F3 Po, F3 N, F3 albedo, F3 view,
                                           Stack& stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
 {
     F3 rgb = f3(0.0f, 0.0f, 0.0f);
@@ -794,19 +807,26 @@ __device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* n
                 rgb.x = fmaf(albedo.x, k, rgb.x);
                 rgb.y = fmaf(albedo.y, k, rgb.y);
                 rgb.z = fmaf(albedo.z, k, rgb.z);
+                if (PHONG && p.phong_ks > 0.0f) {
+                    const float nl2 = 2.0f * dot3(N, Ld);
+                    const F3 R = f3(fmaf(nl2, N.x, -Ld.x), fmaf(nl2, N.y, -Ld.y), fmaf(nl2, N.z, -Ld.z));
+                    const float rv = fmaxf(0.0f, dot3(R, view));
+                    const float sp = (p.phong_ks * (L.intensity / (kFourPi * r2))) * powUint(rv, p.phong_exp);
+                    rgb.x += sp; rgb.y += sp; rgb.z += sp;
+                }
             }
         }
     }
     return rgb;
 }
 
-// mode 100: Lambert + one shadow ray per light, every material treated as diffuse (oracle: shade_lambert)
+// mode 100: Lambert (+ optional Phong highlight) + one shadow ray per light, every material treated as diffuse (oracle: shade_lambert)
 template <bool COUNT, int BLOCK>
 __device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* nodes, const float4* tris, const Ray& r,
                                            const Hit& h, Stack& stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
 {
     const Surface sf = surfaceAt(p, tris, r, h);
-    return directLight<COUNT, BLOCK>(p, nodes, tris, biasPoint(sf.P, sf.N, kShadowBias), sf.N, sf.albedo, stack, iters, cntNodes, cntTris, cntShadow);
+    return directLight<COUNT, BLOCK, true>(p, nodes, tris, biasPoint(sf.P, sf.N, kShadowBias), sf.N, sf.albedo, f3(-r.d.x, -r.d.y, -r.d.z), stack, iters, cntNodes, cntTris, cntShadow);
 }
 
 // ---- mode 200: path tracing (oracle: trace_path). Counter-based RNG keyed by (pixel, sample, seed).
@@ -876,7 +896,7 @@ __device__ __forceinline__ F3 tracePath(const RenderParams& p, const float* camP
         }
         // DIFFUSE and anything else
         const F3 Po = biasPoint(sf.P, sf.N, kShadowBias);
-        const F3 Ld = directLight<COUNT, BLOCK>(p, nodes, tris, Po, sf.N, sf.albedo, stack, iters, cntNodes, cntTris, cntShadow);
+        const F3 Ld = directLight<COUNT, BLOCK, false>(p, nodes, tris, Po, sf.N, sf.albedo, sf.N, stack, iters, cntNodes, cntTris, cntShadow);
         L = f3(fmaf(thr.x, Ld.x, L.x), fmaf(thr.y, Ld.y, L.y), fmaf(thr.z, Ld.z, L.z));
         if (bounce == p.max_bounces) break;
         const float u1 = rngNext(rng), u2 = rngNext(rng);

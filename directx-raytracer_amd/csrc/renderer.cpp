@@ -1,7 +1,9 @@
 #include "renderer.h"
 
+#include <chrono>
 #include <cstdio>
 #include <stdexcept>
+#include <thread>
 
 namespace crt {
 
@@ -89,7 +91,42 @@ void Renderer::renderFrame()
     // updateCameraCB every frame (R/DXRTRenderer.cpp:464)
     check(crt_set_camera(ctx, scene->getCamera().getPosition().data(), scene->getCamera().getRotationMatrix().data()), "crt_set_camera");
     frame.resize(static_cast<size_t>(width) * height * 4);
-    check(crt_render_frame(ctx, width, height, frame.data(), nullptr, nullptr, nullptr, nullptr, &stats), "crt_render_frame");
+    if (nRanks) check(crt_render_frame_distributed(ctx, width, height, nullptr, frame.data(), &stats), "crt_render_frame_distributed");
+    else check(crt_render_frame(ctx, width, height, frame.data(), nullptr, nullptr, nullptr, nullptr, &stats), "crt_render_frame");
+}
+
+void Renderer::setOption(const char* name, int value)
+{
+    if (!ctx) throw std::runtime_error("setOption before prepareForRendering");
+    check(crt_set_option(ctx, name, value), name);
+}
+
+void Renderer::joinRanks(uint32_t rankIn, uint32_t nRanksIn, const std::string& idFile)
+{
+    if (!ctx) throw std::runtime_error("joinRanks before prepareForRendering");
+    unsigned char id[CRT_COMM_ID_BYTES];
+    if (rankIn == 0) {
+        if (crt_comm_unique_id(id) != CRT_OK) throw std::runtime_error(std::string("crt_comm_unique_id: ") + crt_last_error(nullptr));
+        const std::string tmp = idFile + ".tmp";
+        FILE* f = std::fopen(tmp.c_str(), "wb");
+        if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id)) throw std::runtime_error("cannot write '" + tmp + "'");
+        std::fclose(f);
+        if (std::rename(tmp.c_str(), idFile.c_str()) != 0) throw std::runtime_error("cannot publish '" + idFile + "'");
+    } else {
+        bool have = false;
+        for (int tries = 0; tries < 6000 && !have; tries++) { // up to 60 s for rank 0 to come up
+            FILE* f = std::fopen(idFile.c_str(), "rb");
+            if (f) {
+                have = std::fread(id, 1, sizeof(id), f) == sizeof(id);
+                std::fclose(f);
+            }
+            if (!have) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+        if (!have) throw std::runtime_error("rank " + std::to_string(rankIn) + ": no communicator id in '" + idFile + "'");
+    }
+    check(crt_comm_init(ctx, rankIn, nRanksIn, id), "crt_comm_init");
+    rank = rankIn;
+    nRanks = nRanksIn;
 }
 
 void Renderer::stopRendering()

@@ -42,6 +42,14 @@ public:
     void writePPM(const std::string& path) const;
     const crt_frame_stats& getLastFrameStats() const { return stats; }
     void setCounting(bool on);
+    void setOption(const char* name, int value); // crt_set_option: "spp", "max_bounces", "seed", "phong_ks", "phong_exponent", ...
+
+    // N GPUs, one process each (no reference counterpart): join the RCCL communicator of an N-rank run.  Rank 0 creates the
+    // 128-byte id and publishes it as `idFile` (written under a temporary name, then renamed); the other ranks wait for the
+    // file.  Afterwards renderFrame() renders this rank's tiles, gathers and de-interleaves: every rank holds the frame.
+    void joinRanks(uint32_t rank, uint32_t nRanks, const std::string& idFile);
+    uint32_t getRank() const { return rank; }
+    uint32_t getRankCount() const { return nRanks; }
 
 private:
     crt_ctx* ctx = nullptr;
@@ -51,6 +59,7 @@ private:
     bool isChangedShadingMode = true;
     std::vector<uint8_t> frame;
     crt_frame_stats stats{};
+    uint32_t rank = 0, nRanks = 0; // nRanks = 0: single-GPU path (crt_render_frame)
     void uploadScene();
     void check(int rc, const char* what) const;
 };

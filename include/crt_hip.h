@@ -47,7 +47,8 @@ enum {
 #define CRT_MODE_HEIGHT 4u
 #define CRT_MODE_DISTANCE 5u
 #define CRT_MODE_CHECKER 6u
-#define CRT_MODE_LAMBERT 100u /* Lambert + one shadow ray per light (BASELINE.json north_star) */
+#define CRT_MODE_LAMBERT 100u /* Lambert (+ optional Phong highlight, options "phong_ks" / "phong_exponent") + one shadow ray per light
+                                 (BASELINE.json north_star: "Lambert/Phong shading") */
 #define CRT_MODE_PATH 200u    /* path tracing: options "spp" (default 4), "max_bounces" (3), "seed" (1234); BASELINE.json configs[4] */
 
 /* ---- geometry handed over at upload: exactly what createVertexBuffers / createIndexBuffers memcpy ----
@@ -187,7 +188,28 @@ int crt_untile_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_
 int crt_untile_batch_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint32_t n_ranks, uint32_t n_frames, uint32_t frame,
                             const void* d_gathered, void* d_rgba8);
 
-/* options. "gpu_build" 0/1: acceleration structure built on the GPU (LBVH) at the next crt_upload_scene.
+/* ---- native RCCL frame assembly: the N-GPU frame without Python (no reference counterpart: the reference is one GPU, one
+ * DispatchRays, R/DXRTRenderer.cpp:1346-1350, 1405).  One process per GPU, each with its own context and the same scene.
+ * Rank 0 calls crt_comm_unique_id and hands the 128 bytes to the other ranks (file, pipe, MPI: the caller's business); every
+ * rank calls crt_comm_init (collective: returns when all n_ranks have called it).  crt_render_frame_distributed then renders
+ * this rank's macro tiles (crt_render_tiles_device), moves them with ONE ncclAllGather over xGMI -- crt_tile_slots() * 1024 bytes
+ * per rank: 1 044 480 B at 1920x1080 on 8 GPUs, 4 177 920 B on 2 -- and de-interleaves the gathered
+ * buffer; every rank ends up with the whole frame.  Asynchronous on the context's stream unless stats or host_rgba8 is given.
+ * d_rgba8: device frame (w*h*4 bytes) or NULL (a context-owned buffer is used); host_rgba8: optional host copy.
+ * RCCL is loaded at run time (librccl.so.1): a process that never calls these needs no RCCL. */
+#define CRT_COMM_ID_BYTES 128
+int crt_comm_unique_id(void* id_out /* CRT_COMM_ID_BYTES */);
+int crt_comm_init(crt_ctx* ctx, uint32_t rank, uint32_t n_ranks, const void* unique_id);
+int crt_comm_destroy(crt_ctx* ctx);
+int crt_comm_info(const crt_ctx* ctx, uint32_t* rank, uint32_t* n_ranks); /* n_ranks = 0: no communicator */
+int crt_render_frame_distributed(crt_ctx* ctx, uint32_t width, uint32_t height, void* d_rgba8, uint8_t* host_rgba8, crt_frame_stats* stats);
+
+/* options. Phong term of mode 100: the reference's CRTMaterial has no specular coefficient or exponent
+ * (R/CRTMaterial.h:30-35 holds type, albedo, smooth_shading, ior, texture), so both are renderer-wide options invented here:
+ * "phong_ks" = specular coefficient in thousandths (0 = off, the default; 300 = 0.3), "phong_exponent" = integer exponent
+ * 1..65536 (default 32).  Per unoccluded light: rgb += ks * intensity / (4 pi r^2) * max(0, R . V)^n, R = light direction
+ * mirrored about the shading normal, V = direction to the eye; white highlight, x^n by square and multiply.
+ * "gpu_build" 0/1: acceleration structure built on the GPU (LBVH) at the next crt_upload_scene.
  * Rendering parameters of mode 200: "spp", "max_bounces", "seed". Tuning knobs (speed only, results never
  * change): "inner_min" 1..65 wave scheduling of the traversal loop, "xcd_group", "adaptive_order" (launch the most expensive 8x8
  * packets of the previous frame first: 0 never, 1 always, 2 = default: only for a frame issued on the same stream as the frame

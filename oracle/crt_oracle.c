@@ -1190,7 +1190,29 @@ static void surface_at(const oracle_scene* s, const ray* r, const hit_rec* h, su
 /* direct light at Po with normal N: one shadow ray per light whose cosine is positive (BASELINE.json north_star's
  * "Lambert ... + shadow rays"; lights and materials: R/CRTLight.h:4-16, R/CRTMaterial.h:4-36, parsed but never
  * evaluated by the reference -- SURVEY.md section 8 row a13: NOT IN THE REFERENCE, the build's specification) */
-static v3 direct_light(const oracle_scene* s, v3 Po, v3 N, v3 albedo, int brute, trav_count* c, uint64_t* n_shadow)
+/* Phong specular term of mode 100 (NOT in the reference: CRTMaterial has no specular coefficient or exponent,
+ * R/CRTMaterial.h:30-35, so both are renderer options: ks in thousandths, an integer exponent).  x^n by square and multiply
+ * in a fixed order, so that both sides round alike. */
+static float g_phong_ks = 0.0f;
+static uint32_t g_phong_exp = 32;
+void oracle_set_phong(uint32_t ks_permille, uint32_t exponent)
+{
+    g_phong_ks = (float)ks_permille / 1000.0f;
+    g_phong_exp = exponent ? exponent : 1;
+}
+static inline float pow_uint(float x, uint32_t n)
+{
+    float result = 1.0f, base = x;
+    while (n) {
+        if (n & 1u) result *= base;
+        base *= base;
+        n >>= 1;
+    }
+    return result;
+}
+
+/* view = direction from the surface to the eye, or NULL: no specular term (path tracing) */
+static v3 direct_light(const oracle_scene* s, v3 Po, v3 N, v3 albedo, const v3* view, int brute, trav_count* c, uint64_t* n_shadow)
 {
     v3 rgb = v3_make(0.0f, 0.0f, 0.0f);
     for (uint32_t li = 0; li < s->n_lights; li++) {
@@ -1211,6 +1233,13 @@ static v3 direct_light(const oracle_scene* s, v3 Po, v3 N, v3 albedo, int brute,
                 rgb.x = fmaf(albedo.x, k, rgb.x);
                 rgb.y = fmaf(albedo.y, k, rgb.y);
                 rgb.z = fmaf(albedo.z, k, rgb.z);
+                if (view && g_phong_ks > 0.0f) { /* white highlight: the light mirrored about N against the eye direction */
+                    const float nl2 = 2.0f * v3_dot(N, Ld);
+                    const v3 R = v3_make(fmaf(nl2, N.x, -Ld.x), fmaf(nl2, N.y, -Ld.y), fmaf(nl2, N.z, -Ld.z));
+                    const float rv = fmaxf(0.0f, v3_dot(R, *view));
+                    const float sp = (g_phong_ks * (L->intensity / (FOUR_PI * r2))) * pow_uint(rv, g_phong_exp);
+                    rgb.x += sp; rgb.y += sp; rgb.z += sp;
+                }
             }
         }
     }
@@ -1227,7 +1256,8 @@ static v3 shade_lambert(const oracle_scene* s, const ray* r, const hit_rec* h, i
 {
     surface sf;
     surface_at(s, r, h, &sf);
-    return direct_light(s, bias_point(sf.P, sf.N, SHADOW_BIAS), sf.N, sf.albedo, brute, c, n_shadow);
+    const v3 view = v3_make(-r->d.x, -r->d.y, -r->d.z);
+    return direct_light(s, bias_point(sf.P, sf.N, SHADOW_BIAS), sf.N, sf.albedo, &view, brute, c, n_shadow);
 }
 
 /* ------------------------------------------------------------------------------------------------
@@ -1309,7 +1339,7 @@ static v3 trace_path(const oracle_scene* s, const float rot[9], v3 cam, uint32_t
         }
         /* DIFFUSE (and anything else): direct light now, then a cosine-weighted bounce */
         v3 Po = bias_point(sf.P, sf.N, SHADOW_BIAS);
-        v3 Ld = direct_light(s, Po, sf.N, sf.albedo, brute, c, n_shadow);
+        v3 Ld = direct_light(s, Po, sf.N, sf.albedo, NULL, brute, c, n_shadow);
         L = v3_make(fmaf(thr.x, Ld.x, L.x), fmaf(thr.y, Ld.y, L.y), fmaf(thr.z, Ld.z, L.z));
         if (bounce == g_path_bounces) break;
         float u1 = rng_next(&rng), u2 = rng_next(&rng);

@@ -155,6 +155,8 @@ int oracle_render(const oracle_scene* s, const float pos[3], const float rot[9],
 
 /* mode 200 parameters (process-wide): samples per pixel, bounces after the camera ray, RNG seed */
 void oracle_set_path_params(uint32_t spp, uint32_t max_bounces, uint32_t seed);
+/* Phong specular term of mode 100 (extension, see crt_hip.h "phong_ks"): ks in thousandths (0 = off, the default), integer exponent */
+void oracle_set_phong(uint32_t ks_permille, uint32_t exponent);
 void oracle_set_stack_output(uint32_t* max_sp);
 
 /* Small pure functions exposed for known-answer tests. */

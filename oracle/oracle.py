@@ -125,6 +125,8 @@ def lib():
         L.oracle_scene_uvs.argtypes = [C.c_void_p]
         L.oracle_texture_color.argtypes = [C.c_void_p, C.c_float, C.c_float, C.c_void_p]
         L.oracle_set_path_params.argtypes = [C.c_uint32, C.c_uint32, C.c_uint32]
+        L.oracle_set_phong.argtypes = [C.c_uint32, C.c_uint32]
+        L.oracle_set_phong.restype = None
         L.oracle_set_cost_outputs.argtypes = [C.c_void_p] * 4
         L.oracle_set_stack_output.argtypes = [C.c_void_p]
         _lib = L
@@ -329,6 +331,11 @@ def intersect_tri(o, d, v0, v1, v2, tmin=0.001, tmax=10000.0):
 def set_path_params(spp=4, max_bounces=3, seed=1234):
     """mode 200 parameters (process-wide in the oracle)"""
     lib().oracle_set_path_params(int(spp), int(max_bounces), int(seed))
+
+
+def set_phong(ks_permille=0, exponent=32):
+    """Phong specular term of mode 100 (process-wide, like the path parameters); 0 = off"""
+    lib().oracle_set_phong(int(ks_permille), int(exponent))
 
 
 def texture_color(t, u, v):

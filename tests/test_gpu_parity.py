@@ -280,6 +280,37 @@ def test_obj_scene_renders_like_the_oracle(pkg, oracle, scenes, renderer, tmp_pa
     assert (got["hit_inst"] == 0).any() and (got["hit_inst"] == 1).any()  # both objects are in view
 
 
+def test_phong_highlight_matches_the_oracle(pkg, oracle, scenes, dragon, renderer):
+    """north_star's "Lambert/Phong shading": mode 100 with the specular options on (Cornell flat normals, Dragon smooth
+    normals, several coefficients / exponents) is bit-exact against the oracle; with ks = 0 it is the plain Lambert frame."""
+    try:
+        for sc, w, h in ((scenes.cornell_box(), 256, 256), (_with_normals(scenes, dragon), 640, 360)):
+            cam = sc["camera"]
+            renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+            renderer.set_camera(cam["position"], cam["matrix"])
+            renderer.change_shading_mode(100)
+            O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+            plain = renderer.render_frame(w, h)["rgb"].copy()
+            for ks, n in ((300, 32), (1000, 1), (50, 1000), (700, 5)):
+                renderer.set_option("phong_ks", ks)
+                renderer.set_option("phong_exponent", n)
+                oracle.set_phong(ks, n)
+                got = renderer.render_frame(w, h)
+                ref = O.render(cam["position"], cam["matrix"], 100, w, h)
+                for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
+                    np.testing.assert_array_equal(got[k], ref[k], err_msg="ks=%d n=%d %s" % (ks, n, k))
+                assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True), (ks, n)
+                assert (got["rgb"] > plain).any() and not (got["rgb"] < plain).any()
+            renderer.set_option("phong_ks", 0)
+            assert np.array_equal(renderer.render_frame(w, h)["rgb"], plain)
+        with pytest.raises(pkg.CrtError):
+            renderer.set_option("phong_exponent", 0)
+    finally:
+        oracle.set_phong(0, 32)
+        renderer.set_option("phong_ks", 0)
+        renderer.set_option("phong_exponent", 32)
+
+
 def test_pinned_host_frame(pkg, oracle, scenes, renderer):
     """crt_host_alloc: a page-locked output buffer gives the same frame as a pageable one"""
     sc = scenes.cornell_box()
@@ -486,6 +517,114 @@ def test_headless_cpp_driver_matches_binding(pkg, oracle, scenes, dragon, tmp_pa
     # failure is an error message and a non-zero exit code, never an assert/abort
     bad = subprocess.run([exe, str(tmp_path / "nope.crtscene")], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "cannot open" in bad.stderr
+
+
+def _read_ppm(path, w, h):
+    raw = open(path, "rb").read()
+    header_end = raw.index(b"255\n") + 4
+    assert raw[:header_end] == b"P6\n%d %d\n255\n" % (w, h)
+    return np.frombuffer(raw[header_end:], dtype=np.uint8).reshape(h, w, 3)
+
+
+def test_headless_driver_full_camera_controls_and_mode_switch(pkg, oracle, scenes, dragon, tmp_path, golden_dir):
+    """The reference's whole control surface, scripted: A/D -> moveRight (R/DXRTApp.cpp:91-107), wheel -> zoom
+    (R/DXRTViewportWidget.cpp:74-78), mouse -> rotate with pitch, the shading-mode combo box (R/DXRTMainWindow.cpp:114-121),
+    per-frame flags plus a camera-path file, Phong and path-tracing parameters: every frame equals the oracle's for the camera
+    the same Camera calls produce."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "crt_render")
+    scene_file = os.path.join(golden_dir, "dragon.crtscene")
+    path_file = tmp_path / "cam.txt"
+    path_file.write_text("# frame 0: untouched\n\nrotate -4 2; right 0.75\nzoom 0.5; mode 5\npan 3; tilt -2; roll 1.5; forward 0.25\n")
+    prefix = str(tmp_path / "f")
+    w, h, frames = 320, 180, 5
+    out = subprocess.run([exe, scene_file, "--mode", "100", "--size", "%dx%d" % (w, h), "--frames", str(frames), "--orbit", "3", "--pitch", "-1",
+                          "--right", "0.5", "--zoom", "0.125", "--mode-at", "1:3", "--mode-at", "4:100", "--phong", "400:12",
+                          "--path", str(path_file), "--out", prefix], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    sc = _with_normals(scenes, dragon)
+    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    s = pkg.Scene(scene_file)
+    script = {2: lambda: (s.rotate(-4.0, 2.0), s.move_right(0.75)), 3: lambda: s.zoom(0.5),
+              4: lambda: (s.pan(3.0), s.tilt(-2.0), s.roll(1.5), s.move_forward(-0.25))}
+    modes = {0: 100, 1: 3, 2: 3, 3: 5, 4: 100}  # --mode-at 1:3, "mode 5" in the path file at frame 3, --mode-at 4:100
+    try:
+        oracle.set_phong(400, 12)
+        for f in range(frames):
+            if f > 0:
+                s.rotate(3.0, -1.0)
+                s.move_right(0.5)
+                s.zoom(0.125)
+            if f in script:
+                script[f]()
+            pos, rot = s.camera()
+            ref = O.render(pos, rot, modes[f], w, h)["rgba8"][..., :3]
+            np.testing.assert_array_equal(_read_ppm("%s_%d.ppm" % (prefix, f), w, h), ref, err_msg="frame %d" % f)
+    finally:
+        oracle.set_phong(0, 32)
+    # path tracing parameters from the command line
+    out = subprocess.run([exe, scene_file, "--mode", "200", "--size", "160x90", "--spp", "2", "--bounces", "1", "--seed", "77",
+                          "--out", prefix + "p"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    oracle.set_path_params(2, 1, 77)
+    try:
+        s0 = pkg.Scene(scene_file)
+        pos, rot = s0.camera()
+        ref = O.render(pos, rot, 200, 160, 90)["rgba8"][..., :3]
+    finally:
+        oracle.set_path_params(4, 3, 1234)
+    np.testing.assert_array_equal(_read_ppm(prefix + "p_0.ppm", 160, 90), ref)
+    bad = subprocess.run([exe, scene_file, "--path", str(tmp_path / "none.txt")], capture_output=True, text=True, timeout=60)
+    assert bad.returncode == 1 and "camera path" in bad.stderr
+
+
+def test_native_rccl_gather_behind_the_c_abi(pkg, oracle, scenes, dragon, renderer, tmp_path, golden_dir):
+    """crt_comm_init + crt_render_frame_distributed (csrc/crt_api.cpp): tiles -> ncclAllGather on the context's stream ->
+    untile, no torch involved.  With the one rank this box has: the distributed frame equals crt_render_frame_device's and the
+    oracle's; and crt_render --ranks 1 (the C++-only launcher: parent forks the rank processes before touching the GPU) writes
+    the same images as the single-process run."""
+    import subprocess
+    import torch
+    sc = _with_normals(scenes, dragon)
+    cam = sc["camera"]
+    w, h = 1920, 1080
+    r2 = pkg.Renderer(0)
+    try:
+        r2.upload(sc["meshes"], sc["lights"], sc["materials"])
+        r2.set_camera(cam["position"], cam["matrix"])
+        r2.change_shading_mode(100)
+        with pytest.raises(pkg.CrtError):
+            r2.render_frame_distributed(w, h, host=True)  # no communicator yet: CRT_ESTATE
+        uid = r2.comm_init(0, 1)
+        assert len(uid) == 128
+        with pytest.raises(pkg.CrtError):
+            r2.comm_init(0, 1, uid)  # already has one
+        got = r2.render_frame_distributed(w, h, host=True, stats=True)
+        assert got["stats"]["rays_primary"] == w * h and got["stats"]["kernel_ms"] > 0
+        single = r2.render_frame(w, h, want=())["rgba8"]
+        ref = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"]).render(cam["position"], cam["matrix"], 100, w, h, want=("rgba8",))["rgba8"]
+        np.testing.assert_array_equal(got["rgba8"], single)
+        np.testing.assert_array_equal(got["rgba8"], ref)
+        # device-pointer form, several frames in flight on the context's stream, ragged size
+        dev = torch.zeros(333 * 77, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for _ in range(6):
+            r2.render_frame_distributed(333, 77, d_rgba8=dev.data_ptr())
+        r2.synchronize()
+        np.testing.assert_array_equal(dev.cpu().numpy().view(np.uint8).reshape(77, 333, 4), r2.render_frame(333, 77, want=())["rgba8"])
+        r2.comm_destroy()
+        r2.comm_destroy()  # idempotent
+    finally:
+        r2.close()
+    exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "crt_render")
+    scene_file = os.path.join(golden_dir, "dragon.crtscene")
+    common = ["--mode", "100", "--size", "480x270", "--frames", "2", "--orbit", "10"]
+    a = subprocess.run([exe, scene_file] + common + ["--out", str(tmp_path / "one")], capture_output=True, text=True, timeout=300)
+    b = subprocess.run([exe, scene_file] + common + ["--out", str(tmp_path / "ranks"), "--ranks", "1"], capture_output=True, text=True, timeout=300)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr + b.stdout + b.stderr
+    assert "rank 0's tile share of 1 ranks" in b.stdout
+    for f in range(2):
+        np.testing.assert_array_equal(_read_ppm(str(tmp_path / ("one_%d.ppm" % f)), 480, 270), _read_ppm(str(tmp_path / ("ranks_%d.ppm" % f)), 480, 270))
 
 
 def test_context_lifecycle_and_reuse(pkg, oracle, scenes, dragon):

@@ -175,6 +175,32 @@ def test_single_triangle_scene(oracle, scenes):
     assert np.all(out["rgba8"][..., 3] == 255)
 
 
+def test_phong_term_closed_form(oracle, scenes):
+    """Mode 100's optional Phong highlight (an extension: R/CRTMaterial.h:30-35 has no specular fields).  Light at the eye, the
+    centre ray hits the triangle head on: mirror direction = view direction, so the highlight is exactly ks x the Lambert term;
+    off by default; BVH == brute force with it on."""
+    sc = scenes.single_triangle()
+    cam = sc["camera"]
+    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    try:
+        base = O.render(cam["position"], cam["matrix"], 100, 65, 65)["rgb"]
+        oracle.set_phong(500, 7)
+        ph = O.render(cam["position"], cam["matrix"], 100, 65, 65)
+        brute = O.render(cam["position"], cam["matrix"], 100, 65, 65, brute_force=True)
+        q = base[32, 32, 0]
+        assert q > 0 and ph["rgb"][32, 32, 0] == np.float32(q + np.float32(0.5) * q)
+        assert np.array_equal(ph["rgb"], brute["rgb"]) and np.array_equal(ph["rgba8"], brute["rgba8"])
+        hit = ph["hit_inst"] != 0xFFFFFFFF
+        assert np.all(ph["rgb"][hit] >= base[hit]) and np.array_equal(ph["rgb"][~hit], base[~hit])
+        # a larger exponent narrows the highlight: off-centre pixels get less of it, the centre keeps all of it
+        oracle.set_phong(500, 64)
+        narrow = O.render(cam["position"], cam["matrix"], 100, 65, 65)["rgb"]
+        assert narrow[32, 32, 0] == ph["rgb"][32, 32, 0] and np.all(narrow[hit] <= ph["rgb"][hit])
+    finally:
+        oracle.set_phong(0, 32)
+    assert np.array_equal(O.render(cam["position"], cam["matrix"], 100, 65, 65)["rgb"], base)
+
+
 def test_dragon_ground_plane_closed_form(oracle, dragon):
     """Pixels whose closest hit is the ground quad (instance 0, y = -5): t and the colours of modes 4,5,6 depend only
     on the plane, so they are checkable without any BVH (SURVEY.md section 8c iii)."""
