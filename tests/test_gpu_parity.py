@@ -627,6 +627,42 @@ def test_native_rccl_gather_behind_the_c_abi(pkg, oracle, scenes, dragon, render
         np.testing.assert_array_equal(_read_ppm(str(tmp_path / ("one_%d.ppm" % f)), 480, 270), _read_ppm(str(tmp_path / ("ranks_%d.ppm" % f)), 480, 270))
 
 
+def test_reference_scene_layer_bound_to_the_c_abi(pkg, oracle, scenes, dragon, tmp_path, golden_dir):
+    """INTEGRATION.md variant B, compiled and run: integration/DXRTRenderer_hip.cpp -- a DXRTRenderer with the reference's
+    public interface (R/DXRTRenderer.h:74-94) -- over the REFERENCE's own CRT* classes (compiled in place in the build
+    container by oracle/Makefile into oracle/_ref/ref_shim_render, which travels to this box as a binary; the reference's
+    sources do not), bound to libcrt_hip.so.  It loads the Dragon scene with the reference's parser, moves the camera with
+    the reference's CRTCamera and renders modes 0 / 3 / 100; each frame must equal the oracle's for the camera it printed."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "oracle", "_ref", "ref_shim_render")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref/ref_shim_render is built only where the reference tree is mounted")
+    prefix = str(tmp_path / "shim")
+    w, h = 640, 360
+    out = subprocess.run([exe, os.path.join(golden_dir, "dragon.crtscene"), prefix, "%dx%d" % (w, h)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    lines = [l.split() for l in out.stdout.splitlines() if l.startswith("frame ")]
+    assert len(lines) == 3
+    sc = _with_normals(scenes, dragon)
+    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    # the build's own scene layer reaches the same camera states with the same calls (bit for bit here; goldens allow 2e-7)
+    s = pkg.Scene(os.path.join(golden_dir, "dragon.crtscene"))
+    for f, l in enumerate(lines):
+        mode = int(l[3])
+        cam = np.float32([float(x) for x in l[5:17]])
+        ref = O.render(cam[:3], cam[3:], mode, w, h)["rgba8"][..., :3]
+        np.testing.assert_array_equal(_read_ppm("%s_%d.ppm" % (prefix, f), w, h), ref, err_msg="frame %d" % f)
+        if f == 1:
+            s.rotate(20.0, -5.0)
+            s.move_forward(-2.0)
+        if f == 2:
+            s.move_right(1.5)
+            s.zoom(0.25)
+        pos, rot = s.camera()
+        np.testing.assert_allclose(np.concatenate([pos, rot]), cam, rtol=0, atol=2e-6)
+
+
 def test_context_lifecycle_and_reuse(pkg, oracle, scenes, dragon):
     """re-upload, frame-size changes, two contexts at once, NaN vertices, many small frames: no state leaks between
     frames/contexts; results stay the oracle's."""
