@@ -60,6 +60,11 @@ struct RenderParams {
     float batch_pos[3][3];
     float batch_rot[3][9];
     uint32_t* batch_rgba8[3];
+    // mode 200: per-workgroup scratch of the wavefront-private path pipeline (render_kernels.hip pathKernel)
+    unsigned char* path_scratch;  // pathWorkgroupCount() regions of path_region_bytes
+    size_t path_region_bytes;     // pathRegionBytes(path_samples)
+    uint32_t path_tile;           // 16: one workgroup per 16x16 macro tile; 8: one per 8x8 packet
+    uint32_t path_samples;        // samples of the tile carried through the pipeline together: B = tile^2 x this paths (<= 1024)
     unsigned long long* timeline; // counting variant only, nullable: per workgroup {start, end} of s_memrealtime (100 MHz) + XCC id
 };
 
@@ -67,6 +72,9 @@ struct RenderParams {
 int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream);
 // number of work units (= workgroups) launchRender uses for p: size of unit_order / unit_cost
 uint32_t renderUnitCount(const RenderParams& p);
+// mode 200 scratch sizing
+size_t pathRegionBytes(uint32_t tile, uint32_t samples_per_pass);
+uint32_t pathWorkgroupCount(const RenderParams& p);
 // unit_cost -> unit_order (descending)
 int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, ihipStream_t* stream);
 // tile-major gathered buffer -> row-major frame

@@ -48,7 +48,7 @@ constexpr uint32_t kBoostAfter = 300;
 #ifndef CRT_WAVES_PER_EU
 #define CRT_WAVES_PER_EU 7
 #endif
-#define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(PATH ? 1 : CRT_WAVES_PER_EU, 8)))
+#define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(CRT_WAVES_PER_EU, 8)))
 // scalar-cache fetches of records a whole wavefront shares (see loadNodeUniform): in the descent from the root, in any
 // node step whose lanes agree, and in leaves
 #ifndef UNIFORM_DESCENT
@@ -821,12 +821,12 @@ __device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* n
 }
 
 // mode 100: Lambert (+ optional Phong highlight) + one shadow ray per light, every material treated as diffuse (oracle: shade_lambert)
-template <bool COUNT, int BLOCK>
+template <bool COUNT, int BLOCK, bool PHONG>
 __device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* nodes, const float4* tris, const Ray& r,
                                            const Hit& h, Stack& stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
 {
     const Surface sf = surfaceAt(p, tris, r, h);
-    return directLight<COUNT, BLOCK, true>(p, nodes, tris, biasPoint(sf.P, sf.N, kShadowBias), sf.N, sf.albedo, f3(-r.d.x, -r.d.y, -r.d.z), stack, iters, cntNodes, cntTris, cntShadow);
+    return directLight<COUNT, BLOCK, PHONG>(p, nodes, tris, biasPoint(sf.P, sf.N, kShadowBias), sf.N, sf.albedo, f3(-r.d.x, -r.d.y, -r.d.z), stack, iters, cntNodes, cntTris, cntShadow);
 }
 
 // ---- mode 200: path tracing (oracle: trace_path). Counter-based RNG keyed by (pixel, sample, seed).
@@ -842,86 +842,15 @@ __device__ __forceinline__ float rngNext(uint32_t& st)
     return static_cast<float>(st >> 8) * 0x1p-24f;
 }
 
-template <bool COUNT, int BLOCK>
-__device__ __forceinline__ F3 tracePath(const RenderParams& p, const float* camPos, const float* camRot, const float4* nodes, const float4* tris, uint32_t px, uint32_t py,
-                                        uint32_t pix, uint32_t sample, Stack& stack, Hit& firstHit, uint32_t& iters,
-                                        uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow, uint32_t& cntClosest)
-{
-    uint32_t rng = pcgHash(pix ^ pcgHash(sample + pcgHash(p.seed)));
-    const float jx = rngNext(rng), jy = rngNext(rng);
-    Ray r = makeRay(f3(camPos[0], camPos[1], camPos[2]), rayDirJ(camRot, px, py, jx, jy, static_cast<float>(p.width), static_cast<float>(p.height)));
-    F3 L = f3(0.0f, 0.0f, 0.0f), thr = f3(1.0f, 1.0f, 1.0f);
-    const F3 miss = f3(p.miss[0], p.miss[1], p.miss[2]);
-    float tmin = kTMin;
-    for (uint32_t bounce = 0;; bounce++) {
-        Hit h;
-        if (COUNT) cntClosest++;
-        traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, tmin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, iters, cntNodes, cntTris);
-        if (bounce == 0 && sample == 0) firstHit = h;
-        if (!(h.t < kTMax)) {
-            L = f3(fmaf(thr.x, miss.x, L.x), fmaf(thr.y, miss.y, L.y), fmaf(thr.z, miss.z, L.z));
-            break;
-        }
-        const Surface sf = surfaceAt(p, tris, r, h);
-        tmin = 0.0f;
-        if (sf.mtype == 4u) { // CONSTANT
-            L = f3(fmaf(thr.x, sf.albedo.x, L.x), fmaf(thr.y, sf.albedo.y, L.y), fmaf(thr.z, sf.albedo.z, L.z));
-            break;
-        }
-        if (sf.mtype == 2u) { // REFLECTIVE
-            if (bounce == p.max_bounces) break;
-            const float k = 2.0f * dot3(r.d, sf.N);
-            const F3 d = normalize3(f3(fmaf(-k, sf.N.x, r.d.x), fmaf(-k, sf.N.y, r.d.y), fmaf(-k, sf.N.z, r.d.z)));
-            thr = f3(thr.x * sf.albedo.x, thr.y * sf.albedo.y, thr.z * sf.albedo.z);
-            r = makeRay(biasPoint(sf.P, sf.N, kShadowBias), d);
-            continue;
-        }
-        if (sf.mtype == 3u) { // REFRACTIVE
-            if (bounce == p.max_bounces) break;
-            const float eta = sf.entering ? 1.0f / sf.ior : sf.ior;
-            const float cosi = -dot3(r.d, sf.N);
-            const float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
-            F3 d, o;
-            if (k < 0.0f) {
-                const float m = 2.0f * dot3(r.d, sf.N);
-                d = f3(fmaf(-m, sf.N.x, r.d.x), fmaf(-m, sf.N.y, r.d.y), fmaf(-m, sf.N.z, r.d.z));
-                o = biasPoint(sf.P, sf.N, kShadowBias);
-            } else {
-                const float m = eta * cosi - sqrtf(k);
-                d = f3(fmaf(m, sf.N.x, eta * r.d.x), fmaf(m, sf.N.y, eta * r.d.y), fmaf(m, sf.N.z, eta * r.d.z));
-                o = biasPoint(sf.P, sf.N, -kShadowBias);
-            }
-            r = makeRay(o, normalize3(d));
-            continue;
-        }
-        // DIFFUSE and anything else
-        const F3 Po = biasPoint(sf.P, sf.N, kShadowBias);
-        const F3 Ld = directLight<COUNT, BLOCK, false>(p, nodes, tris, Po, sf.N, sf.albedo, sf.N, stack, iters, cntNodes, cntTris, cntShadow);
-        L = f3(fmaf(thr.x, Ld.x, L.x), fmaf(thr.y, Ld.y, L.y), fmaf(thr.z, Ld.z, L.z));
-        if (bounce == p.max_bounces) break;
-        const float u1 = rngNext(rng), u2 = rngNext(rng);
-        const float rr = sqrtf(u1), phi = 6.28318530717958648f * u2;
-        const float lx = rr * sinContract(phi + 1.57079632679489662f), ly = rr * sinContract(phi), lz = sqrtf(fmaxf(0.0f, 1.0f - u1));
-        const float sg = copysignf(1.0f, sf.N.z);
-        const float a = -1.0f / (sg + sf.N.z);
-        const float b = sf.N.x * sf.N.y * a;
-        const F3 T = f3(1.0f + sg * sf.N.x * sf.N.x * a, sg * b, -sg * sf.N.x);
-        const F3 B = f3(b, sg + sf.N.y * sf.N.y * a, -sf.N.y);
-        const F3 d = f3(fmaf(lz, sf.N.x, fmaf(ly, B.x, lx * T.x)), fmaf(lz, sf.N.y, fmaf(ly, B.y, lx * T.y)),
-                        fmaf(lz, sf.N.z, fmaf(ly, B.z, lx * T.z)));
-        thr = f3(thr.x * sf.albedo.x, thr.y * sf.albedo.y, thr.z * sf.albedo.z);
-        r = makeRay(Po, normalize3(d));
-    }
-    return L;
-}
-
 __device__ __forceinline__ uint32_t waveSum(uint32_t v)
 {
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
     return v;
 }
 
-template <bool COUNT, bool PATH>
+// PHONG: the specular term of mode 100 is compiled into its own variant (chosen at launch when "phong_ks" is non-zero), so
+// that the plain Lambert kernel keeps its register budget
+template <bool COUNT, bool PHONG>
 __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const RenderParams p)
 {
     extern __shared__ int s_stack[]; // stack_entries x 256 dwords, sized at launch from the BVH depth
@@ -1006,18 +935,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
         F3 col;
         uint32_t inst = 0xFFFFFFFFu, prim = 0xFFFFFFFFu;
         Hit h;
-        if (PATH) {
-            // mode 200: spp jittered samples averaged; the hit outputs report sample 0's camera ray
-            const uint32_t pixId = py * p.width + px;
-            F3 acc = f3(0.0f, 0.0f, 0.0f);
-            h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
-            for (uint32_t sm = 0; sm < p.spp; sm++) {
-                const F3 Ls = tracePath<COUNT, BLOCK>(p, camPos, camRot, nodes, tris, px, py, pixId, sm, stack, h, iters, cntNodes, cntTris, cntShadow, cntClosest);
-                acc = f3(acc.x + Ls.x, acc.y + Ls.y, acc.z + Ls.z);
-            }
-            const float inv = 1.0f / static_cast<float>(p.spp);
-            col = f3(acc.x * inv, acc.y * inv, acc.z * inv);
-        } else {
+        {
             const F3 o = f3(camPos[0], camPos[1], camPos[2]);
             const Ray r = makeRay(o, rayDir(camRot, px, py, static_cast<float>(p.width), static_cast<float>(p.height)));
             if (COUNT) cntClosest++;
@@ -1025,7 +943,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
             col = f3(p.miss[0], p.miss[1], p.miss[2]); // miss shader (hlsl:72-76)
             if (h.t < kTMax) {
                 const float4* T = tris + 3 * static_cast<size_t>(h.tri);
-                if (p.mode >= 100u) col = shadeLambert<COUNT, BLOCK>(p, nodes, tris, r, h, stack, iters, cntNodes, cntTris, cntShadow);
+                if (p.mode >= 100u) col = shadeLambert<COUNT, BLOCK, PHONG>(p, nodes, tris, r, h, stack, iters, cntNodes, cntTris, cntShadow);
                 else col = shadeDebug(p.mode, __float_as_uint(T[0].w), __float_as_uint(T[1].w), h.t, h.u, h.v, r.o, r.d);
             }
         }
@@ -1091,6 +1009,313 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
     }
 }
 
+// ---- mode 200: path tracing as a wavefront-private pipeline (oracle: trace_path; replaces the per-lane bounce loop, which
+// kept 22 % of the lanes busy: a lane whose path had ended idled until the longest path of its wavefront ended).
+//
+// One workgroup = one wavefront = one pixel tile x `path_samples` samples = B paths: by default an 8x8 packet x up to 16
+// samples (256 paths at 4 spp); option "path_tile" = 16 makes it a 16x16 macro tile x 4 samples (longer queues, fewer
+// workgroups: slower at both 1080p and 4K).  The wavefront
+// runs the whole pipeline for ITS paths by stages, 64 paths at a time, with two private queues in HBM scratch:
+//   stage A  camera rays of the tile (coherent 8x8 packets, octant-specialised scalar-fetch descent), closest hit;
+//            a miss finishes the path, a hit is appended to the shade queue;
+//   stage B  every entry of the shade queue: surface, material, direct light (any-hit shadow rays), next direction; a path
+//            that ends writes its radiance, one that goes on is appended to the trace queue;
+//   stage C  every entry of the trace queue: closest hit of the bounce ray; miss -> finished, hit -> shade queue; back to B.
+// Appending = wavefront ballot + prefix count (mbcnt) + a scalar running count: every stage works on dense 64-path
+// chunks, no atomics, no cross-wavefront traffic, no kernel boundary, and the queues are streamed with coalesced dwordx4
+// accesses (record i of a queue = one float4 per plane at index i).  Per path the arithmetic -- RNG stream, radiance
+// updates, their order -- is the oracle's, so frames stay bit-exact; the sample average runs in sample order at the end.
+// Samples beyond `path_samples` are further passes of the same wavefront over the same scratch.
+constexpr uint32_t kShadePlanes = 5, kTracePlanes = 4;
+
+struct PathScratch {
+    float4* shade;   // kShadePlanes x B: {o, rng} {d, id} {thr, t} {L, u} {v, tri, -, -}
+    float4* trace;   // kTracePlanes x B: {o, rng} {d, id} {thr, -} {L, -}
+    float4* done;    // B: final radiance of path (sample-in-pass * 256 + pixel-in-tile)
+    float4* accum;   // 256: running sum over the samples of earlier passes
+    uint32_t B;
+};
+
+__device__ __forceinline__ uint32_t lanePrefix(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+}
+
+#ifndef CRT_PATH_WAVES_PER_EU
+#define CRT_PATH_WAVES_PER_EU 5
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAVES_PER_EU, 8))) void pathKernel(const RenderParams p)
+{
+    extern __shared__ int s_stack[];
+    const uint32_t frame = p.n_batch > 1u ? blockIdx.x % p.n_batch : 0u;
+    const uint32_t wg = p.n_batch > 1u ? blockIdx.x / p.n_batch : blockIdx.x;
+    const bool big = p.path_tile == 16u;                  // workgroup = whole macro tile (four 8x8 packets per sample) or one 8x8 packet
+    const uint32_t j = big ? wg : wg >> 2;                // position of the macro tile in this rank's list
+    const uint32_t subFirst = big ? 0u : (wg & 3u), subCount = big ? 4u : 1u;
+    const uint32_t tilePixels = subCount * 64u;
+    const float* camPos = frame ? p.batch_pos[frame - 1u] : p.pos;
+    const float* camRot = frame ? p.batch_rot[frame - 1u] : p.rot;
+    uint32_t* outRgba8 = frame ? p.batch_rgba8[frame - 1u] : p.rgba8;
+    uint32_t tile_x, tile_y;
+    bool valid;
+    if (p.n_ranks == 1) {
+        const uint32_t blocks_x = (p.tiles_x + 3u) >> 2;
+        const uint32_t blk = j >> 4, within = j & 15u;
+        tile_x = (blk % blocks_x) * 4u + (within & 3u);
+        tile_y = (blk / blocks_x) * 4u + (within >> 2);
+        valid = (tile_x < p.tiles_x) & (tile_y < p.tiles_y);
+    } else {
+        const uint32_t k = j * p.n_ranks + p.rank;
+        valid = k < p.tiles_x * p.tiles_y;
+        tile_x = k % p.tiles_x;
+        tile_y = k / p.tiles_x;
+    }
+    if (!valid) return;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const float4* nodes = reinterpret_cast<const float4*>(p.nodes);
+    const float4* tris = reinterpret_cast<const float4*>(p.tris);
+    Stack stack;
+    stack.lds = s_stack + lane;
+    stack.spill = p.spill + (static_cast<size_t>(blockIdx.x) * 64u + lane) * p.spill_stride;
+    stack.cap = static_cast<int>(p.stack_entries);
+    stack.sp = 0;
+    constexpr int BLOCK = 64;
+    const int innerMin = static_cast<int>(p.tune_inner_min);
+
+    PathScratch q;
+    q.B = tilePixels * p.path_samples;
+    {
+        float4* base = reinterpret_cast<float4*>(p.path_scratch + static_cast<size_t>(blockIdx.x) * p.path_region_bytes);
+        q.shade = base;
+        q.trace = q.shade + static_cast<size_t>(kShadePlanes) * q.B;
+        q.done = q.trace + static_cast<size_t>(kTracePlanes) * q.B;
+        q.accum = q.done + q.B;
+    }
+    const F3 miss = f3(p.miss[0], p.miss[1], p.miss[2]);
+    uint32_t cntNodes = 0, cntTris = 0, cntShadow = 0, cntClosest = 0, iters = 0;
+
+    for (uint32_t s0 = 0; s0 < p.spp; s0 += p.path_samples) {
+        const uint32_t nS = min(p.path_samples, p.spp - s0);
+        uint32_t nShade = 0; // wave-uniform queue lengths
+        // ---- stage A: the tile's camera rays, one 8x8 packet of one sample at a time
+        for (uint32_t sl = 0; sl < nS; sl++) {
+            for (uint32_t sb = 0; sb < subCount; sb++) {
+                const uint32_t sub = subFirst + sb;
+                const uint32_t lx = (sub & 1u) * 8u + (lane & 7u), ly = (sub >> 1) * 8u + (lane >> 3);
+                const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
+                const bool active = (px < p.width) & (py < p.height);
+                const uint32_t id = sl * tilePixels + sb * 64u + lane; // path id inside the workgroup
+                bool isHit = false;
+                Ray r;
+                Hit h;
+                uint32_t rng = 0;
+                if (active) {
+                    const uint32_t pixId = py * p.width + px;
+                    rng = pcgHash(pixId ^ pcgHash((s0 + sl) + pcgHash(p.seed)));
+                    const float jx = rngNext(rng), jy = rngNext(rng);
+                    r = makeRay(f3(camPos[0], camPos[1], camPos[2]), rayDirJ(camRot, px, py, jx, jy, static_cast<float>(p.width), static_cast<float>(p.height)));
+                    if (COUNT) cntClosest++;
+                    traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, innerMin, h, iters, cntNodes, cntTris);
+                    isHit = h.t < kTMax;
+                    if (!isHit) q.done[id] = make_float4(fmaf(1.0f, miss.x, 0.0f), fmaf(1.0f, miss.y, 0.0f), fmaf(1.0f, miss.z, 0.0f), 0.0f);
+                    if (s0 + sl == 0u && frame == 0u) { // the hit outputs report sample 0's camera ray
+                        const size_t pix = static_cast<size_t>(py) * p.width + px;
+                        uint32_t inst = 0xFFFFFFFFu, prim = 0xFFFFFFFFu;
+                        if (isHit) {
+                            const float4* T = tris + 3 * static_cast<size_t>(h.tri);
+                            inst = __float_as_uint(T[0].w);
+                            prim = __float_as_uint(T[1].w);
+                        }
+                        if (p.hit_inst) p.hit_inst[pix] = inst;
+                        if (p.hit_prim) p.hit_prim[pix] = prim;
+                        if (p.hit_t) p.hit_t[pix] = isHit ? h.t : kTMax;
+                    }
+                }
+                const unsigned long long m = __ballot(isHit);
+                if (isHit) {
+                    const uint32_t i = nShade + lanePrefix(m);
+                    q.shade[i] = make_float4(r.o.x, r.o.y, r.o.z, __uint_as_float(rng));
+                    q.shade[q.B + i] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(id)); // bounce 0 in the upper half
+                    q.shade[2u * q.B + i] = make_float4(1.0f, 1.0f, 1.0f, h.t);
+                    q.shade[3u * q.B + i] = make_float4(0.0f, 0.0f, 0.0f, h.u);
+                    q.shade[4u * q.B + i] = make_float4(h.v, __uint_as_float(h.tri), 0.0f, 0.0f);
+                }
+                nShade += static_cast<uint32_t>(__popcll(m));
+            }
+        }
+        // ---- stages B / C until no path is left
+        while (nShade != 0u) {
+            uint32_t nTrace = 0;
+            for (uint32_t c = 0; c < nShade; c += 64u) { // stage B
+                const uint32_t i = c + lane;
+                // Only what the shadow-ray traversal needs stays in registers across it (shading point, normal, albedo); throughput,
+                // radiance, RNG state and path id are read back from the queue record afterwards.
+                bool alive = false, diffuse = false;
+                F3 no = f3(0.f, 0.f, 0.f), nd = f3(0.f, 0.f, 0.f), N = f3(0.f, 0.f, 0.f), albedo = f3(0.f, 0.f, 0.f);
+                float thrMul = 0.0f; // 1: throughput *= albedo on the way out (REFLECTIVE, DIFFUSE)
+                if (i < nShade) {
+                    const float4 a0 = q.shade[i], a1 = q.shade[q.B + i];
+                    const Ray r = makeRay(f3(a0.x, a0.y, a0.z), f3(a1.x, a1.y, a1.z));
+                    const uint32_t bounce = __float_as_uint(a1.w) >> 16;
+                    Hit h;
+                    h.t = q.shade[2u * q.B + i].w; h.u = q.shade[3u * q.B + i].w;
+                    const float4 a4 = q.shade[4u * q.B + i];
+                    h.v = a4.x; h.tri = __float_as_uint(a4.y); h.gid = 0;
+                    const Surface sf = surfaceAt(p, tris, r, h);
+                    N = sf.N;
+                    albedo = sf.albedo;
+                    if (sf.mtype == 4u) { // CONSTANT: radiance += throughput * albedo, path ends (thrMul = -1 marks it)
+                        thrMul = -1.0f;
+                    } else if (sf.mtype == 2u) { // REFLECTIVE
+                        if (bounce != p.max_bounces) {
+                            const float k = 2.0f * dot3(r.d, sf.N);
+                            nd = normalize3(f3(fmaf(-k, sf.N.x, r.d.x), fmaf(-k, sf.N.y, r.d.y), fmaf(-k, sf.N.z, r.d.z)));
+                            no = biasPoint(sf.P, sf.N, kShadowBias);
+                            thrMul = 1.0f;
+                            alive = true;
+                        }
+                    } else if (sf.mtype == 3u) { // REFRACTIVE
+                        if (bounce != p.max_bounces) {
+                            const float eta = sf.entering ? 1.0f / sf.ior : sf.ior;
+                            const float cosi = -dot3(r.d, sf.N);
+                            const float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+                            F3 d;
+                            if (k < 0.0f) {
+                                const float m2 = 2.0f * dot3(r.d, sf.N);
+                                d = f3(fmaf(-m2, sf.N.x, r.d.x), fmaf(-m2, sf.N.y, r.d.y), fmaf(-m2, sf.N.z, r.d.z));
+                                no = biasPoint(sf.P, sf.N, kShadowBias);
+                            } else {
+                                const float m2 = eta * cosi - sqrtf(k);
+                                d = f3(fmaf(m2, sf.N.x, eta * r.d.x), fmaf(m2, sf.N.y, eta * r.d.y), fmaf(m2, sf.N.z, eta * r.d.z));
+                                no = biasPoint(sf.P, sf.N, -kShadowBias);
+                            }
+                            nd = normalize3(d);
+                            alive = true;
+                        }
+                    } else { // DIFFUSE and anything else
+                        diffuse = true;
+                        no = biasPoint(sf.P, sf.N, kShadowBias);
+                    }
+                }
+                F3 Ld = f3(0.0f, 0.0f, 0.0f);
+                if (diffuse) Ld = directLight<COUNT, BLOCK, false>(p, nodes, tris, no, N, albedo, N, stack, iters, cntNodes, cntTris, cntShadow);
+                F3 thr = f3(0.f, 0.f, 0.f), L = f3(0.f, 0.f, 0.f);
+                uint32_t rng = 0, idb = 0;
+                if (i < nShade) {
+                    const float4 a2 = q.shade[2u * q.B + i], a3 = q.shade[3u * q.B + i];
+                    rng = __float_as_uint(q.shade[i].w);
+                    idb = __float_as_uint(q.shade[q.B + i].w);
+                    thr = f3(a2.x, a2.y, a2.z);
+                    L = f3(a3.x, a3.y, a3.z);
+                    if (thrMul < 0.0f) L = f3(fmaf(thr.x, albedo.x, L.x), fmaf(thr.y, albedo.y, L.y), fmaf(thr.z, albedo.z, L.z));
+                    if (diffuse) {
+                        L = f3(fmaf(thr.x, Ld.x, L.x), fmaf(thr.y, Ld.y, L.y), fmaf(thr.z, Ld.z, L.z));
+                        if ((idb >> 16) != p.max_bounces) {
+                            const float u1 = rngNext(rng), u2 = rngNext(rng);
+                            const float rr = sqrtf(u1), phi = 6.28318530717958648f * u2;
+                            const float lx = rr * sinContract(phi + 1.57079632679489662f), ly = rr * sinContract(phi), lz = sqrtf(fmaxf(0.0f, 1.0f - u1));
+                            const float sg = copysignf(1.0f, N.z);
+                            const float a = -1.0f / (sg + N.z);
+                            const float b = N.x * N.y * a;
+                            const F3 T = f3(1.0f + sg * N.x * N.x * a, sg * b, -sg * N.x);
+                            const F3 Bv = f3(b, sg + N.y * N.y * a, -N.y);
+                            const F3 d = f3(fmaf(lz, N.x, fmaf(ly, Bv.x, lx * T.x)), fmaf(lz, N.y, fmaf(ly, Bv.y, lx * T.y)),
+                                            fmaf(lz, N.z, fmaf(ly, Bv.z, lx * T.z)));
+                            nd = normalize3(d);
+                            thrMul = 1.0f;
+                            alive = true;
+                        }
+                    }
+                    if (thrMul > 0.0f) thr = f3(thr.x * albedo.x, thr.y * albedo.y, thr.z * albedo.z);
+                    if (!alive) q.done[idb & 0xFFFFu] = make_float4(L.x, L.y, L.z, 0.0f);
+                }
+                const unsigned long long m = __ballot(alive);
+                if (alive) {
+                    const uint32_t k = nTrace + lanePrefix(m);
+                    q.trace[k] = make_float4(no.x, no.y, no.z, __uint_as_float(rng));
+                    q.trace[q.B + k] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(idb + 0x10000u)); // next bounce
+                    q.trace[2u * q.B + k] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+                    q.trace[3u * q.B + k] = make_float4(L.x, L.y, L.z, 0.0f);
+                }
+                nTrace += static_cast<uint32_t>(__popcll(m));
+            }
+            nShade = 0;
+            for (uint32_t c = 0; c < nTrace; c += 64u) { // stage C
+                const uint32_t i = c + lane;
+                bool isHit = false;
+                Hit h;
+                if (i < nTrace) {
+                    const float4 a0 = q.trace[i], a1 = q.trace[q.B + i];
+                    const Ray r = makeRay(f3(a0.x, a0.y, a0.z), f3(a1.x, a1.y, a1.z));
+                    if (COUNT) cntClosest++;
+                    traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, 0.0f, kTMax, stack, innerMin, h, iters, cntNodes, cntTris);
+                    isHit = h.t < kTMax;
+                }
+                const unsigned long long m = __ballot(isHit);
+                if (i < nTrace) { // the record is read again after the traversal rather than held in registers across it
+                    const float4 a0 = q.trace[i], a1 = q.trace[q.B + i], a2 = q.trace[2u * q.B + i], a3 = q.trace[3u * q.B + i];
+                    if (isHit) {
+                        const uint32_t k = nShade + lanePrefix(m);
+                        q.shade[k] = a0;
+                        q.shade[q.B + k] = a1;
+                        q.shade[2u * q.B + k] = make_float4(a2.x, a2.y, a2.z, h.t);
+                        q.shade[3u * q.B + k] = make_float4(a3.x, a3.y, a3.z, h.u);
+                        q.shade[4u * q.B + k] = make_float4(h.v, __uint_as_float(h.tri), 0.0f, 0.0f);
+                    } else {
+                        q.done[__float_as_uint(a1.w) & 0xFFFFu] = make_float4(fmaf(a2.x, miss.x, a3.x), fmaf(a2.y, miss.y, a3.y), fmaf(a2.z, miss.z, a3.z), 0.0f);
+                    }
+                }
+                nShade += static_cast<uint32_t>(__popcll(m));
+            }
+        }
+        // ---- this pass's samples join the running sums in sample order; after the last pass: average, quantise, store
+        const bool last = s0 + nS >= p.spp;
+        for (uint32_t sb = 0; sb < subCount; sb++) {
+            const uint32_t sub = subFirst + sb;
+            const uint32_t lx = (sub & 1u) * 8u + (lane & 7u), ly = (sub >> 1) * 8u + (lane >> 3);
+            const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
+            if ((px < p.width) & (py < p.height)) {
+                const uint32_t pl = sb * 64u + lane;
+                F3 acc = f3(0.0f, 0.0f, 0.0f);
+                if (s0 != 0u) {
+                    const float4 a = q.accum[pl];
+                    acc = f3(a.x, a.y, a.z);
+                }
+                for (uint32_t sl = 0; sl < nS; sl++) {
+                    const float4 Ls = q.done[sl * tilePixels + pl];
+                    acc = f3(acc.x + Ls.x, acc.y + Ls.y, acc.z + Ls.z);
+                }
+                if (!last) {
+                    q.accum[pl] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+                } else {
+                    const float inv = 1.0f / static_cast<float>(p.spp);
+                    const F3 col = f3(acc.x * inv, acc.y * inv, acc.z * inv);
+                    const uint32_t packed = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
+                    const size_t pix = static_cast<size_t>(py) * p.width + px;
+                    if (p.staging) outRgba8[static_cast<size_t>((tile_y * p.tiles_x + tile_x) / p.n_ranks) * (kTile * kTile) + ly * kTile + lx] = packed;
+                    else outRgba8[pix] = packed;
+                    if (p.rgb_f32 && frame == 0u) {
+                        p.rgb_f32[3 * pix + 0] = col.x;
+                        p.rgb_f32[3 * pix + 1] = col.y;
+                        p.rgb_f32[3 * pix + 2] = col.z;
+                    }
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        const uint32_t a = waveSum(cntNodes), c = waveSum(cntTris), sh = waveSum(cntShadow), cl = waveSum(cntClosest);
+        if (lane == 0) {
+            atomicAdd(&p.counters[0], static_cast<unsigned long long>(a));
+            atomicAdd(&p.counters[1], static_cast<unsigned long long>(c));
+            atomicAdd(&p.counters[2], static_cast<unsigned long long>(sh));
+            atomicAdd(&p.counters[3], static_cast<unsigned long long>(cl));
+        }
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void untileKernel(const uint32_t* __restrict__ gathered, uint32_t* __restrict__ frame,
                                                        uint32_t width, uint32_t height, uint32_t tiles_x, uint32_t n_ranks,
                                                        uint32_t rank_stride, uint32_t first_slot)
@@ -1116,18 +1341,32 @@ uint32_t renderUnitCount(const RenderParams& p)
     return n * 4u;
 }
 
+// scratch the path-tracing pipeline needs per workgroup (one macro tile): the two queues, the finished-path radiances and
+// the cross-pass sums; and how many workgroups launchRender starts for p in mode 200
+size_t pathRegionBytes(uint32_t tile, uint32_t samples_per_pass)
+{
+    const size_t pixels = static_cast<size_t>(tile) * tile, B = pixels * samples_per_pass;
+    return (kShadePlanes + kTracePlanes + 1u) * B * sizeof(float4) + pixels * sizeof(float4);
+}
+uint32_t pathWorkgroupCount(const RenderParams& p) { return renderUnitCount(p) / (p.path_tile == 16u ? 4u : 1u) * (p.n_batch ? p.n_batch : 1u); }
+
 int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream)
 {
     if (p.n_local_tiles == 0) return 0;
     // list length: single GPU walks whole 4x4-tile blocks (padded at the frame edges); then padded to 8 XCDs x kGroupMax
     const uint32_t n = renderUnitCount(p) / 4u;
-    const dim3 grid(n * 4u * (p.n_batch ? p.n_batch : 1u)), block(64);
+    const dim3 block(64);
     const size_t lds = static_cast<size_t>(p.stack_entries) * 64u * sizeof(int);
-    if (p.mode >= 200u) {
-        if (counting) hipLaunchKernelGGL((renderKernel<true, true>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((renderKernel<false, true>), grid, block, lds, stream, p);
+    if (p.mode >= 200u) { // one wavefront per macro tile carries all its paths through the pipeline
+        const dim3 grid(pathWorkgroupCount(p));
+        if (counting) hipLaunchKernelGGL((pathKernel<true>), grid, block, lds, stream, p);
+        else hipLaunchKernelGGL((pathKernel<false>), grid, block, lds, stream, p);
     } else {
-        if (counting) hipLaunchKernelGGL((renderKernel<true, false>), grid, block, lds, stream, p);
+        const dim3 grid(n * 4u * (p.n_batch ? p.n_batch : 1u));
+        const bool phong = p.mode >= 100u && p.phong_ks > 0.0f;
+        if (counting && phong) hipLaunchKernelGGL((renderKernel<true, true>), grid, block, lds, stream, p);
+        else if (counting) hipLaunchKernelGGL((renderKernel<true, false>), grid, block, lds, stream, p);
+        else if (phong) hipLaunchKernelGGL((renderKernel<false, true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((renderKernel<false, false>), grid, block, lds, stream, p);
     }
     return static_cast<int>(hipGetLastError());

@@ -15,7 +15,7 @@ import csv, glob, collections, statistics
 acc = collections.defaultdict(list)
 for f in glob.glob("$OUT/pass*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "renderKernel<false, true>" in r["Kernel_Name"]:
+        if "pathKernel<false>" in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(acc.items()):
     print("%-28s %18.1f  (%d launches)" % (k, statistics.median(v), len(v)))
