@@ -388,93 +388,49 @@ __device__ __forceinline__ void nodeStepAnyAt(const NodeRegs& nd, const Ray& r, 
 // node steps are issued while at least `innerMin` lanes still stand on inner nodes (or nobody waits at a leaf); then the
 // lanes waiting at leaves intersect their triangles.  innerMin = 1 is the classic while-while loop (leaves wait until
 // every lane has one: 47 % of the lanes active on the 1M-triangle frame); 32 measured best (first measurement: 0.67 vs 1.10 ms; re-swept after every structural change).
+// One scheduling decision of the closest-hit traversal for the whole wavefront: NODE_STEPS node steps of the lanes standing
+// on inner nodes, or the leaf step of the lanes waiting at leaves.  Per-lane state (cur, stack, h, tcull) lives in the
+// caller, so a caller may retire finished rays and start new ones between two calls (streamClosest).  Returns false when
+// no lane has anything left to do.
 template <bool COUNT, int BLOCK, int OCT>
-__device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes, const float4* __restrict__ tris,
-                                             uint32_t n_nodes, const Ray& r, float tmin, float tmax, Stack& stack, int innerMin,
-                                             Hit& h, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris)
+__device__ __forceinline__ bool closestIteration(const float4* __restrict__ nodes, const float4* __restrict__ tris, const Ray& r, float tmin,
+                                                 float& tcull, Stack& stack, int innerMin, Hit& h, int& cur, uint32_t& iters,
+                                                 uint32_t& cntNodes, uint32_t& cntTris)
 {
-    h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
-    int cur = n_nodes ? 0 : kDone;
-    stack.sp = 0;
-    float tcull = tmax * kCullPad; // boxes are culled against best_t * pad; changes only when a hit is accepted
-    CRT_UNIFORM_DESCENT(nodeStepClosestAt)
-    for (;;) {
-        const unsigned long long innerMask = __ballot(cur >= 0);
-        const unsigned long long leafMask = __ballot((cur < 0) & (cur != kDone));
-        if ((innerMask | leafMask) == 0ull) break;
-        if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3); // a wavefront on a long critical path stops queueing behind the others
-        if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
+    const unsigned long long innerMask = __ballot(cur >= 0);
+    const unsigned long long leafMask = __ballot((cur < 0) & (cur != kDone));
+    if ((innerMask | leafMask) == 0ull) return false;
+    if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3); // a wavefront on a long critical path stops queueing behind the others
+    if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
 #if CRT_PROF
-            const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
 #pragma unroll
-            for (int rep = 0; rep < NODE_STEPS; rep++) { // several node steps per scheduling decision: fewer ballots/branches
-                if (cur >= 0) CRT_NODE_STEP(nodeStepClosestAt)
-            }
-#if CRT_PROF
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            stack.tNode += __builtin_amdgcn_s_memtime() - ts0; stack.itNode++; stack.lanesNode += __popcll(innerMask);
-#endif
-            continue;
+        for (int rep = 0; rep < NODE_STEPS; rep++) { // several node steps per scheduling decision: fewer ballots/branches
+            if (cur >= 0) CRT_NODE_STEP(nodeStepClosestAt)
         }
 #if CRT_PROF
-        const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
-        stack.itLeaf++; stack.lanesLeaf += __popcll(leafMask);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stack.tNode += __builtin_amdgcn_s_memtime() - ts0; stack.itNode++; stack.lanesNode += __popcll(innerMask);
 #endif
-        if ((cur < 0) & (cur != kDone)) {
-            const uint32_t code = static_cast<uint32_t>(~cur);
-            const uint32_t first = code >> 3, cnt = code & 7u;
+        return true;
+    }
+#if CRT_PROF
+    const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+    stack.itLeaf++; stack.lanesLeaf += __popcll(leafMask);
+#endif
+    if ((cur < 0) & (cur != kDone)) {
+        const uint32_t code = static_cast<uint32_t>(~cur);
+        const uint32_t first = code >> 3, cnt = code & 7u;
 #if UNIFORM_LEAF
-            const int lc0 = __builtin_amdgcn_readfirstlane(cur);
-            if (__ballot(cur != lc0) == 0ull) {
-                // every waiting lane stands on the same leaf: its triangles come through the scalar cache, once per wavefront
-                const uint32_t ucode = static_cast<uint32_t>(~lc0);
-                const uint32_t ufirst = ucode >> 3, ucnt = ucode & 7u;
-                for (uint32_t i = ufirst; i < ufirst + ucnt; i++) {
-                    float4 a, b, c;
-                    loadTriUniform(tris + 3 * static_cast<size_t>(i), a, b, c);
-                    if (COUNT) cntTris++;
-                    float t, u, v;
-                    if (triTest(r, a, b, c, tmin, t, u, v)) {
-                        const uint32_t gid = __float_as_uint(c.w);
-                        if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
-                            h.t = t; h.u = u; h.v = v; h.tri = i; h.gid = gid;
-                            tcull = t * kCullPad;
-                        }
-                    }
-                }
-            } else
-#endif
-#if LEAF_PAIRS
-            CRT_DIV_STATS_LEAF
-            // two triangles per memory round trip (same test order): the second record's loads overlap the first's
-            for (uint32_t i = first; i < first + cnt; i += 2) {
-                const bool two = i + 1 < first + cnt;
-                const float4* T = tris + 3 * static_cast<size_t>(i);
-                const float4* T1 = two ? T + 3 : T;
-                const float4 a = T[0], b = T[1], c = T[2];
-                const float4 a1 = T1[0], b1 = T1[1], c1 = T1[2];
-                if (COUNT) cntTris += two ? 2u : 1u;
-                float t, u, v;
-                if (triTest(r, a, b, c, tmin, t, u, v)) {
-                    const uint32_t gid = __float_as_uint(c.w);
-                    if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
-                        h.t = t; h.u = u; h.v = v; h.tri = i; h.gid = gid;
-                        tcull = t * kCullPad;
-                    }
-                }
-                if (two & triTest(r, a1, b1, c1, tmin, t, u, v)) {
-                    const uint32_t gid = __float_as_uint(c1.w);
-                    if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
-                        h.t = t; h.u = u; h.v = v; h.tri = i + 1; h.gid = gid;
-                        tcull = t * kCullPad;
-                    }
-                }
-            }
-#else
-            for (uint32_t i = first; i < first + cnt; i++) {
-                const float4* T = tris + 3 * static_cast<size_t>(i);
-                const float4 a = T[0], b = T[1], c = T[2];
+        const int lc0 = __builtin_amdgcn_readfirstlane(cur);
+        if (__ballot(cur != lc0) == 0ull) {
+            // every waiting lane stands on the same leaf: its triangles come through the scalar cache, once per wavefront
+            const uint32_t ucode = static_cast<uint32_t>(~lc0);
+            const uint32_t ufirst = ucode >> 3, ucnt = ucode & 7u;
+            for (uint32_t i = ufirst; i < ufirst + ucnt; i++) {
+                float4 a, b, c;
+                loadTriUniform(tris + 3 * static_cast<size_t>(i), a, b, c);
                 if (COUNT) cntTris++;
                 float t, u, v;
                 if (triTest(r, a, b, c, tmin, t, u, v)) {
@@ -485,14 +441,136 @@ __device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes
                     }
                 }
             }
+        } else
 #endif
-            cur = stack.sp == 0 ? kDone : stack.pop();
+#if LEAF_PAIRS
+        CRT_DIV_STATS_LEAF
+        // two triangles per memory round trip (same test order): the second record's loads overlap the first's
+        for (uint32_t i = first; i < first + cnt; i += 2) {
+            const bool two = i + 1 < first + cnt;
+            const float4* T = tris + 3 * static_cast<size_t>(i);
+            const float4* T1 = two ? T + 3 : T;
+            const float4 a = T[0], b = T[1], c = T[2];
+            const float4 a1 = T1[0], b1 = T1[1], c1 = T1[2];
+            if (COUNT) cntTris += two ? 2u : 1u;
+            float t, u, v;
+            if (triTest(r, a, b, c, tmin, t, u, v)) {
+                const uint32_t gid = __float_as_uint(c.w);
+                if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
+                    h.t = t; h.u = u; h.v = v; h.tri = i; h.gid = gid;
+                    tcull = t * kCullPad;
+                }
+            }
+            if (two & triTest(r, a1, b1, c1, tmin, t, u, v)) {
+                const uint32_t gid = __float_as_uint(c1.w);
+                if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
+                    h.t = t; h.u = u; h.v = v; h.tri = i + 1; h.gid = gid;
+                    tcull = t * kCullPad;
+                }
+            }
+        }
+#else
+        for (uint32_t i = first; i < first + cnt; i++) {
+            const float4* T = tris + 3 * static_cast<size_t>(i);
+            const float4 a = T[0], b = T[1], c = T[2];
+            if (COUNT) cntTris++;
+            float t, u, v;
+            if (triTest(r, a, b, c, tmin, t, u, v)) {
+                const uint32_t gid = __float_as_uint(c.w);
+                if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
+                    h.t = t; h.u = u; h.v = v; h.tri = i; h.gid = gid;
+                    tcull = t * kCullPad;
+                }
+            }
+        }
+#endif
+        cur = stack.sp == 0 ? kDone : stack.pop();
+    }
+#if CRT_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    stack.tLeaf += __builtin_amdgcn_s_memtime() - tl0;
+#endif
+    return true;
+}
+
+template <bool COUNT, int BLOCK, int OCT>
+__device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                             uint32_t n_nodes, const Ray& r, float tmin, float tmax, Stack& stack, int innerMin,
+                                             Hit& h, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris)
+{
+    h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
+    int cur = n_nodes ? 0 : kDone;
+    stack.sp = 0;
+    float tcull = tmax * kCullPad; // boxes are culled against best_t * pad; changes only when a hit is accepted
+    CRT_UNIFORM_DESCENT(nodeStepClosestAt)
+    while (closestIteration<COUNT, BLOCK, OCT>(nodes, tris, r, tmin, tcull, stack, innerMin, h, cur, iters, cntNodes, cntTris)) {}
+}
+
+// One scheduling decision of the any-hit traversal (see closestIteration); tmax / tcull / occluded are per-lane state of the caller
+template <bool COUNT, int BLOCK, int OCT>
+__device__ __forceinline__ bool anyIteration(const float4* __restrict__ nodes, const float4* __restrict__ tris, const Ray& r, float tmin, float tmax,
+                                             float tcull, Stack& stack, int innerMin, bool& occluded, int& cur, uint32_t& iters,
+                                             uint32_t& cntNodes, uint32_t& cntTris)
+{
+    const unsigned long long innerMask = __ballot(cur >= 0);
+    const unsigned long long leafMask = __ballot((cur < 0) & (cur != kDone));
+    if ((innerMask | leafMask) == 0ull) return false;
+    if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3);
+    if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
+#if CRT_PROF
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+        for (int rep = 0; rep < NODE_STEPS; rep++) {
+            if (cur >= 0) CRT_NODE_STEP(nodeStepAnyAt)
         }
 #if CRT_PROF
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        stack.tLeaf += __builtin_amdgcn_s_memtime() - tl0;
+        stack.tNode += __builtin_amdgcn_s_memtime() - ts0; stack.itNode++; stack.lanesNode += __popcll(innerMask);
 #endif
+        return true;
     }
+#if CRT_PROF
+    const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+    stack.itLeaf++; stack.lanesLeaf += __popcll(leafMask);
+#endif
+    if ((cur < 0) & (cur != kDone)) {
+        const uint32_t code = static_cast<uint32_t>(~cur);
+        const uint32_t first = code >> 3, cnt = code & 7u;
+#if UNIFORM_LEAF
+        const int lc0 = __builtin_amdgcn_readfirstlane(cur);
+        if (__ballot(cur != lc0) == 0ull) {
+            const uint32_t ucode = static_cast<uint32_t>(~lc0);
+            const uint32_t ufirst = ucode >> 3, ucnt = ucode & 7u;
+            for (uint32_t i = ufirst; i < ufirst + ucnt; i++) {
+                float4 a, b, c;
+                loadTriUniform(tris + 3 * static_cast<size_t>(i), a, b, c);
+                if (COUNT) cntTris++;
+                float t, u, v;
+                if (triTest(r, a, b, c, tmin, t, u, v) & (t < tmax)) {
+                    occluded = true;
+                    break;
+                }
+            }
+        } else
+#endif
+        for (uint32_t i = first; i < first + cnt; i++) {
+            const float4* T = tris + 3 * static_cast<size_t>(i);
+            const float4 a = T[0], b = T[1], c = T[2];
+            if (COUNT) cntTris++;
+            float t, u, v;
+            if (triTest(r, a, b, c, tmin, t, u, v) & (t < tmax)) {
+                occluded = true;
+                break;
+            }
+        }
+        cur = (occluded | (stack.sp == 0)) ? kDone : stack.pop();
+    }
+#if CRT_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    stack.tLeaf += __builtin_amdgcn_s_memtime() - tl0;
+#endif
+    return true;
 }
 
 template <bool COUNT, int BLOCK, int OCT>
@@ -505,66 +583,7 @@ __device__ __forceinline__ bool traceAnyOct(const float4* __restrict__ nodes, co
     stack.sp = 0;
     const float tcull = tmax * kCullPad;
     CRT_UNIFORM_DESCENT(nodeStepAnyAt)
-    for (;;) {
-        const unsigned long long innerMask = __ballot(cur >= 0);
-        const unsigned long long leafMask = __ballot((cur < 0) & (cur != kDone));
-        if ((innerMask | leafMask) == 0ull) break;
-        if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3);
-        if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
-#if CRT_PROF
-            const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
-#endif
-#pragma unroll
-            for (int rep = 0; rep < NODE_STEPS; rep++) {
-                if (cur >= 0) CRT_NODE_STEP(nodeStepAnyAt)
-            }
-#if CRT_PROF
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            stack.tNode += __builtin_amdgcn_s_memtime() - ts0; stack.itNode++; stack.lanesNode += __popcll(innerMask);
-#endif
-            continue;
-        }
-#if CRT_PROF
-        const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
-        stack.itLeaf++; stack.lanesLeaf += __popcll(leafMask);
-#endif
-        if ((cur < 0) & (cur != kDone)) {
-            const uint32_t code = static_cast<uint32_t>(~cur);
-            const uint32_t first = code >> 3, cnt = code & 7u;
-#if UNIFORM_LEAF
-            const int lc0 = __builtin_amdgcn_readfirstlane(cur);
-            if (__ballot(cur != lc0) == 0ull) {
-                const uint32_t ucode = static_cast<uint32_t>(~lc0);
-                const uint32_t ufirst = ucode >> 3, ucnt = ucode & 7u;
-                for (uint32_t i = ufirst; i < ufirst + ucnt; i++) {
-                    float4 a, b, c;
-                    loadTriUniform(tris + 3 * static_cast<size_t>(i), a, b, c);
-                    if (COUNT) cntTris++;
-                    float t, u, v;
-                    if (triTest(r, a, b, c, tmin, t, u, v) & (t < tmax)) {
-                        occluded = true;
-                        break;
-                    }
-                }
-            } else
-#endif
-            for (uint32_t i = first; i < first + cnt; i++) {
-                const float4* T = tris + 3 * static_cast<size_t>(i);
-                const float4 a = T[0], b = T[1], c = T[2];
-                if (COUNT) cntTris++;
-                float t, u, v;
-                if (triTest(r, a, b, c, tmin, t, u, v) & (t < tmax)) {
-                    occluded = true;
-                    break;
-                }
-            }
-            cur = (occluded | (stack.sp == 0)) ? kDone : stack.pop();
-        }
-#if CRT_PROF
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        stack.tLeaf += __builtin_amdgcn_s_memtime() - tl0;
-#endif
-    }
+    while (anyIteration<COUNT, BLOCK, OCT>(nodes, tris, r, tmin, tmax, tcull, stack, innerMin, occluded, cur, iters, cntNodes, cntTris)) {}
     return occluded;
 }
 
@@ -1041,6 +1060,232 @@ __device__ __forceinline__ uint32_t lanePrefix(unsigned long long m)
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
 }
 
+// Stage C as a stream: the bounce rays of the trace queue are incoherent and their traversals differ a lot in length, so
+// a chunk-at-a-time loop leaves most lanes idle while the longest ray of each chunk finishes.  Here a lane that has finished
+// retires its ray (miss -> radiance written, hit -> appended to the shade queue) and takes the next entry of the queue,
+// as soon as at least `refillMin` lanes are idle: the wavefront stays full until the queue runs dry.  Every ray is still
+// traced by one lane in its own fixed order, so results and fetch counts are those of the chunked loop.
+#ifndef CRT_REFILL_MIN
+#define CRT_REFILL_MIN 16
+#endif
+template <bool COUNT>
+__device__ __forceinline__ void streamClosest(const float4* __restrict__ nodes, const float4* __restrict__ tris, uint32_t n_nodes,
+                                              const PathScratch& q, uint32_t nTrace, uint32_t& nShade, F3 miss, Stack& stack, int innerMin,
+                                              uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntClosest)
+{
+    constexpr int BLOCK = 64;
+    Ray r = makeRay(f3(0.0f, 0.0f, 0.0f), f3(0.0f, 0.0f, 1.0f));
+    Hit h;
+    h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
+    float tcull = kTMax * kCullPad;
+    int cur = kDone;
+    bool have = false;   // this lane holds a ray (being traced, or finished and not yet retired)
+    uint32_t my = 0;     // its index in the trace queue
+    uint32_t next = 0;   // wave-uniform: first queue entry not yet handed to a lane
+    const unsigned long long all = __ballot(true);
+    for (;;) {
+        const bool idle = cur == kDone;
+        const unsigned long long idleMask = __ballot(idle);
+        if (idleMask == all || (next < nTrace && static_cast<uint32_t>(__popcll(idleMask)) >= static_cast<uint32_t>(CRT_REFILL_MIN))) {
+            // retire the finished rays ...
+            const bool retire = idle & have, isHit = retire & (h.t < kTMax);
+            const unsigned long long mh = __ballot(isHit);
+            if (retire) {
+                const float4 a0 = q.trace[my], a1 = q.trace[q.B + my], a2 = q.trace[2u * q.B + my], a3 = q.trace[3u * q.B + my];
+                if (isHit) {
+                    const uint32_t k = nShade + lanePrefix(mh);
+                    q.shade[k] = a0;
+                    q.shade[q.B + k] = a1;
+                    q.shade[2u * q.B + k] = make_float4(a2.x, a2.y, a2.z, h.t);
+                    q.shade[3u * q.B + k] = make_float4(a3.x, a3.y, a3.z, h.u);
+                    q.shade[4u * q.B + k] = make_float4(h.v, __uint_as_float(h.tri), 0.0f, 0.0f);
+                } else {
+                    q.done[__float_as_uint(a1.w) & 0xFFFFu] = make_float4(fmaf(a2.x, miss.x, a3.x), fmaf(a2.y, miss.y, a3.y), fmaf(a2.z, miss.z, a3.z), 0.0f);
+                }
+            }
+            nShade += static_cast<uint32_t>(__popcll(mh));
+            // ... and hand the next queue entries to the idle lanes
+            const uint32_t idx = next + lanePrefix(idleMask);
+            if (idle) {
+                have = idx < nTrace;
+                if (have) {
+                    my = idx;
+                    const float4 a0 = q.trace[idx], a1 = q.trace[q.B + idx];
+                    r = makeRay(f3(a0.x, a0.y, a0.z), f3(a1.x, a1.y, a1.z));
+                    h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
+                    tcull = kTMax * kCullPad;
+                    stack.sp = 0;
+                    cur = n_nodes ? 0 : kDone;
+                    if (COUNT) cntClosest++;
+                }
+            }
+            next += static_cast<uint32_t>(__popcll(idleMask));
+            if (__ballot(have) == 0ull) break; // queue empty and every ray retired
+        }
+        closestIteration<COUNT, BLOCK, 8>(nodes, tris, r, 0.0f, tcull, stack, innerMin, h, cur, iters, cntNodes, cntTris);
+    }
+}
+
+// Stage B as a stream (same idea as streamClosest): the entries of the shade queue are shaded by whichever lane is free.
+// A lane's life with one entry: fetch (surface, material; mirror / glass / constant finish at once) -> for each light with a
+// positive cosine, in light order: one any-hit shadow ray, its contribution added when unoccluded (oracle: direct_light) ->
+// retire (radiance update, next direction drawn, appended to the trace queue or written out as finished).  Shadow rays end at
+// their first hit, so their traversals differ even more in length than the bounce rays': refilling keeps the wavefront full.
+template <bool COUNT>
+__device__ __forceinline__ void streamShade(const RenderParams& p, const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                            const PathScratch& q, uint32_t nShade, uint32_t& nTrace, Stack& stack, int innerMin,
+                                            uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
+{
+    constexpr int BLOCK = 64;
+    const LightRec* lights = reinterpret_cast<const LightRec*>(p.lights);
+    Ray sr = makeRay(f3(0.0f, 0.0f, 0.0f), f3(0.0f, 0.0f, 1.0f)); // the shadow ray in flight
+    float dist = 0.0f, tcull = 0.0f, kcur = 0.0f;                  // its length, cull bound, and the light's weight if it arrives
+    bool occluded = false;
+    int cur = kDone;
+    bool have = false, diffuse = false, tracing = false, alive = false;
+    float thrMul = 0.0f;  // 1: throughput *= albedo when the path goes on; -1: CONSTANT (radiance += throughput * albedo)
+    uint32_t my = 0, li = 0;
+    F3 Po = f3(0.f, 0.f, 0.f), N = f3(0.f, 0.f, 1.f), albedo = f3(0.f, 0.f, 0.f);
+    F3 aux = f3(0.f, 0.f, 0.f); // DIFFUSE: direct light gathered so far; REFLECTIVE / REFRACTIVE: the next direction
+    uint32_t next = 0;
+    const unsigned long long all = __ballot(true);
+    for (;;) {
+        const bool idle = cur == kDone;
+        const unsigned long long idleMask = __ballot(idle);
+        if (idleMask == all || (next < nShade && static_cast<uint32_t>(__popcll(idleMask)) >= static_cast<uint32_t>(CRT_REFILL_MIN))) {
+            // 1. a shadow ray has come back: its light counts unless something is in the way
+            if (idle & tracing) {
+                if (!occluded) aux = f3(fmaf(albedo.x, kcur, aux.x), fmaf(albedo.y, kcur, aux.y), fmaf(albedo.z, kcur, aux.z));
+                tracing = false;
+                li++;
+            }
+            // 2. retire: the entries whose lights are all done (or that never had any to ask)
+            const bool retire = idle & have & !(diffuse & (li < p.n_lights));
+            F3 thr = f3(0.f, 0.f, 0.f), L = f3(0.f, 0.f, 0.f), nd = f3(0.f, 0.f, 0.f);
+            uint32_t rng = 0, idb = 0;
+            bool goesOn = false;
+            if (retire) {
+                const float4 a2 = q.shade[2u * q.B + my], a3 = q.shade[3u * q.B + my];
+                rng = __float_as_uint(q.shade[my].w);
+                idb = __float_as_uint(q.shade[q.B + my].w);
+                thr = f3(a2.x, a2.y, a2.z);
+                L = f3(a3.x, a3.y, a3.z);
+                goesOn = alive;
+                nd = aux;
+                if (thrMul < 0.0f) L = f3(fmaf(thr.x, albedo.x, L.x), fmaf(thr.y, albedo.y, L.y), fmaf(thr.z, albedo.z, L.z));
+                if (diffuse) {
+                    L = f3(fmaf(thr.x, aux.x, L.x), fmaf(thr.y, aux.y, L.y), fmaf(thr.z, aux.z, L.z));
+                    if ((idb >> 16) != p.max_bounces) {
+                        const float u1 = rngNext(rng), u2 = rngNext(rng);
+                        const float rr = sqrtf(u1), phi = 6.28318530717958648f * u2;
+                        const float lx = rr * sinContract(phi + 1.57079632679489662f), ly = rr * sinContract(phi), lz = sqrtf(fmaxf(0.0f, 1.0f - u1));
+                        const float sg = copysignf(1.0f, N.z);
+                        const float a = -1.0f / (sg + N.z);
+                        const float b = N.x * N.y * a;
+                        const F3 T = f3(1.0f + sg * N.x * N.x * a, sg * b, -sg * N.x);
+                        const F3 Bv = f3(b, sg + N.y * N.y * a, -N.y);
+                        const F3 d = f3(fmaf(lz, N.x, fmaf(ly, Bv.x, lx * T.x)), fmaf(lz, N.y, fmaf(ly, Bv.y, lx * T.y)),
+                                        fmaf(lz, N.z, fmaf(ly, Bv.z, lx * T.z)));
+                        nd = normalize3(d);
+                        thrMul = 1.0f;
+                        goesOn = true;
+                    }
+                }
+                if (thrMul > 0.0f) thr = f3(thr.x * albedo.x, thr.y * albedo.y, thr.z * albedo.z);
+                if (!goesOn) q.done[idb & 0xFFFFu] = make_float4(L.x, L.y, L.z, 0.0f);
+                have = false;
+            }
+            const unsigned long long mOn = __ballot(goesOn);
+            if (goesOn) {
+                const uint32_t k = nTrace + lanePrefix(mOn);
+                q.trace[k] = make_float4(Po.x, Po.y, Po.z, __uint_as_float(rng));
+                q.trace[q.B + k] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(idb + 0x10000u)); // next bounce
+                q.trace[2u * q.B + k] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+                q.trace[3u * q.B + k] = make_float4(L.x, L.y, L.z, 0.0f);
+            }
+            nTrace += static_cast<uint32_t>(__popcll(mOn));
+            // 3. fetch: the lanes without an entry take the next ones of the queue
+            const bool wantNew = idle & !have;
+            const unsigned long long mNew = __ballot(wantNew);
+            const uint32_t idx = next + lanePrefix(mNew);
+            if (wantNew && idx < nShade) {
+                have = true;
+                my = idx;
+                const float4 a0 = q.shade[idx], a1 = q.shade[q.B + idx];
+                const Ray r = makeRay(f3(a0.x, a0.y, a0.z), f3(a1.x, a1.y, a1.z));
+                const uint32_t bounce = __float_as_uint(a1.w) >> 16;
+                Hit h;
+                h.t = q.shade[2u * q.B + idx].w; h.u = q.shade[3u * q.B + idx].w;
+                const float4 a4 = q.shade[4u * q.B + idx];
+                h.v = a4.x; h.tri = __float_as_uint(a4.y); h.gid = 0;
+                const Surface sf = surfaceAt(p, tris, r, h);
+                N = sf.N;
+                albedo = sf.albedo;
+                diffuse = false; alive = false; thrMul = 0.0f; li = 0;
+                aux = f3(0.0f, 0.0f, 0.0f);
+                Po = biasPoint(sf.P, sf.N, kShadowBias);
+                if (sf.mtype == 4u) { // CONSTANT
+                    thrMul = -1.0f;
+                } else if (sf.mtype == 2u) { // REFLECTIVE
+                    if (bounce != p.max_bounces) {
+                        const float k = 2.0f * dot3(r.d, sf.N);
+                        aux = normalize3(f3(fmaf(-k, sf.N.x, r.d.x), fmaf(-k, sf.N.y, r.d.y), fmaf(-k, sf.N.z, r.d.z)));
+                        thrMul = 1.0f;
+                        alive = true;
+                    }
+                } else if (sf.mtype == 3u) { // REFRACTIVE
+                    if (bounce != p.max_bounces) {
+                        const float eta = sf.entering ? 1.0f / sf.ior : sf.ior;
+                        const float cosi = -dot3(r.d, sf.N);
+                        const float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+                        F3 d;
+                        if (k < 0.0f) {
+                            const float m2 = 2.0f * dot3(r.d, sf.N);
+                            d = f3(fmaf(-m2, sf.N.x, r.d.x), fmaf(-m2, sf.N.y, r.d.y), fmaf(-m2, sf.N.z, r.d.z));
+                        } else {
+                            const float m2 = eta * cosi - sqrtf(k);
+                            d = f3(fmaf(m2, sf.N.x, eta * r.d.x), fmaf(m2, sf.N.y, eta * r.d.y), fmaf(m2, sf.N.z, eta * r.d.z));
+                            Po = biasPoint(sf.P, sf.N, -kShadowBias);
+                        }
+                        aux = normalize3(d);
+                        alive = true;
+                    }
+                } else {
+                    diffuse = true;
+                }
+            }
+            next += static_cast<uint32_t>(__popcll(mNew));
+            // 4. the next light of every diffuse entry that is not waiting for a shadow ray
+            if ((cur == kDone) & have & diffuse & !tracing) {
+                while (li < p.n_lights) {
+                    const LightRec Lt = lights[li];
+                    const F3 Lv = sub3(f3(Lt.x, Lt.y, Lt.z), Po);
+                    const float r2 = dot3(Lv, Lv);
+                    const float d1 = sqrtf(r2);
+                    const float invr = 1.0f / d1;
+                    const F3 Ldir = f3(Lv.x * invr, Lv.y * invr, Lv.z * invr);
+                    const float cosv = fmaxf(0.0f, dot3(N, Ldir));
+                    if (cosv > 0.0f) {
+                        sr = makeRay(Po, Ldir);
+                        dist = d1;
+                        tcull = d1 * kCullPad;
+                        kcur = (Lt.intensity / (kFourPi * r2)) * cosv;
+                        occluded = false;
+                        tracing = true;
+                        stack.sp = 0;
+                        cur = p.n_nodes ? 0 : kDone;
+                        if (COUNT) cntShadow++;
+                        break;
+                    }
+                    li++;
+                }
+            }
+            if (__ballot(have) == 0ull) break;
+        }
+        anyIteration<COUNT, BLOCK, 8>(nodes, tris, sr, 0.0f, dist, tcull, stack, innerMin, occluded, cur, iters, cntNodes, cntTris);
+    }
+}
+
 #ifndef CRT_PATH_WAVES_PER_EU
 #define CRT_PATH_WAVES_PER_EU 5
 #endif
@@ -1148,127 +1393,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
         // ---- stages B / C until no path is left
         while (nShade != 0u) {
             uint32_t nTrace = 0;
-            for (uint32_t c = 0; c < nShade; c += 64u) { // stage B
-                const uint32_t i = c + lane;
-                // Only what the shadow-ray traversal needs stays in registers across it (shading point, normal, albedo); throughput,
-                // radiance, RNG state and path id are read back from the queue record afterwards.
-                bool alive = false, diffuse = false;
-                F3 no = f3(0.f, 0.f, 0.f), nd = f3(0.f, 0.f, 0.f), N = f3(0.f, 0.f, 0.f), albedo = f3(0.f, 0.f, 0.f);
-                float thrMul = 0.0f; // 1: throughput *= albedo on the way out (REFLECTIVE, DIFFUSE)
-                if (i < nShade) {
-                    const float4 a0 = q.shade[i], a1 = q.shade[q.B + i];
-                    const Ray r = makeRay(f3(a0.x, a0.y, a0.z), f3(a1.x, a1.y, a1.z));
-                    const uint32_t bounce = __float_as_uint(a1.w) >> 16;
-                    Hit h;
-                    h.t = q.shade[2u * q.B + i].w; h.u = q.shade[3u * q.B + i].w;
-                    const float4 a4 = q.shade[4u * q.B + i];
-                    h.v = a4.x; h.tri = __float_as_uint(a4.y); h.gid = 0;
-                    const Surface sf = surfaceAt(p, tris, r, h);
-                    N = sf.N;
-                    albedo = sf.albedo;
-                    if (sf.mtype == 4u) { // CONSTANT: radiance += throughput * albedo, path ends (thrMul = -1 marks it)
-                        thrMul = -1.0f;
-                    } else if (sf.mtype == 2u) { // REFLECTIVE
-                        if (bounce != p.max_bounces) {
-                            const float k = 2.0f * dot3(r.d, sf.N);
-                            nd = normalize3(f3(fmaf(-k, sf.N.x, r.d.x), fmaf(-k, sf.N.y, r.d.y), fmaf(-k, sf.N.z, r.d.z)));
-                            no = biasPoint(sf.P, sf.N, kShadowBias);
-                            thrMul = 1.0f;
-                            alive = true;
-                        }
-                    } else if (sf.mtype == 3u) { // REFRACTIVE
-                        if (bounce != p.max_bounces) {
-                            const float eta = sf.entering ? 1.0f / sf.ior : sf.ior;
-                            const float cosi = -dot3(r.d, sf.N);
-                            const float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
-                            F3 d;
-                            if (k < 0.0f) {
-                                const float m2 = 2.0f * dot3(r.d, sf.N);
-                                d = f3(fmaf(-m2, sf.N.x, r.d.x), fmaf(-m2, sf.N.y, r.d.y), fmaf(-m2, sf.N.z, r.d.z));
-                                no = biasPoint(sf.P, sf.N, kShadowBias);
-                            } else {
-                                const float m2 = eta * cosi - sqrtf(k);
-                                d = f3(fmaf(m2, sf.N.x, eta * r.d.x), fmaf(m2, sf.N.y, eta * r.d.y), fmaf(m2, sf.N.z, eta * r.d.z));
-                                no = biasPoint(sf.P, sf.N, -kShadowBias);
-                            }
-                            nd = normalize3(d);
-                            alive = true;
-                        }
-                    } else { // DIFFUSE and anything else
-                        diffuse = true;
-                        no = biasPoint(sf.P, sf.N, kShadowBias);
-                    }
-                }
-                F3 Ld = f3(0.0f, 0.0f, 0.0f);
-                if (diffuse) Ld = directLight<COUNT, BLOCK, false>(p, nodes, tris, no, N, albedo, N, stack, iters, cntNodes, cntTris, cntShadow);
-                F3 thr = f3(0.f, 0.f, 0.f), L = f3(0.f, 0.f, 0.f);
-                uint32_t rng = 0, idb = 0;
-                if (i < nShade) {
-                    const float4 a2 = q.shade[2u * q.B + i], a3 = q.shade[3u * q.B + i];
-                    rng = __float_as_uint(q.shade[i].w);
-                    idb = __float_as_uint(q.shade[q.B + i].w);
-                    thr = f3(a2.x, a2.y, a2.z);
-                    L = f3(a3.x, a3.y, a3.z);
-                    if (thrMul < 0.0f) L = f3(fmaf(thr.x, albedo.x, L.x), fmaf(thr.y, albedo.y, L.y), fmaf(thr.z, albedo.z, L.z));
-                    if (diffuse) {
-                        L = f3(fmaf(thr.x, Ld.x, L.x), fmaf(thr.y, Ld.y, L.y), fmaf(thr.z, Ld.z, L.z));
-                        if ((idb >> 16) != p.max_bounces) {
-                            const float u1 = rngNext(rng), u2 = rngNext(rng);
-                            const float rr = sqrtf(u1), phi = 6.28318530717958648f * u2;
-                            const float lx = rr * sinContract(phi + 1.57079632679489662f), ly = rr * sinContract(phi), lz = sqrtf(fmaxf(0.0f, 1.0f - u1));
-                            const float sg = copysignf(1.0f, N.z);
-                            const float a = -1.0f / (sg + N.z);
-                            const float b = N.x * N.y * a;
-                            const F3 T = f3(1.0f + sg * N.x * N.x * a, sg * b, -sg * N.x);
-                            const F3 Bv = f3(b, sg + N.y * N.y * a, -N.y);
-                            const F3 d = f3(fmaf(lz, N.x, fmaf(ly, Bv.x, lx * T.x)), fmaf(lz, N.y, fmaf(ly, Bv.y, lx * T.y)),
-                                            fmaf(lz, N.z, fmaf(ly, Bv.z, lx * T.z)));
-                            nd = normalize3(d);
-                            thrMul = 1.0f;
-                            alive = true;
-                        }
-                    }
-                    if (thrMul > 0.0f) thr = f3(thr.x * albedo.x, thr.y * albedo.y, thr.z * albedo.z);
-                    if (!alive) q.done[idb & 0xFFFFu] = make_float4(L.x, L.y, L.z, 0.0f);
-                }
-                const unsigned long long m = __ballot(alive);
-                if (alive) {
-                    const uint32_t k = nTrace + lanePrefix(m);
-                    q.trace[k] = make_float4(no.x, no.y, no.z, __uint_as_float(rng));
-                    q.trace[q.B + k] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(idb + 0x10000u)); // next bounce
-                    q.trace[2u * q.B + k] = make_float4(thr.x, thr.y, thr.z, 0.0f);
-                    q.trace[3u * q.B + k] = make_float4(L.x, L.y, L.z, 0.0f);
-                }
-                nTrace += static_cast<uint32_t>(__popcll(m));
-            }
+            streamShade<COUNT>(p, nodes, tris, q, nShade, nTrace, stack, innerMin, iters, cntNodes, cntTris, cntShadow); // stage B
             nShade = 0;
-            for (uint32_t c = 0; c < nTrace; c += 64u) { // stage C
-                const uint32_t i = c + lane;
-                bool isHit = false;
-                Hit h;
-                if (i < nTrace) {
-                    const float4 a0 = q.trace[i], a1 = q.trace[q.B + i];
-                    const Ray r = makeRay(f3(a0.x, a0.y, a0.z), f3(a1.x, a1.y, a1.z));
-                    if (COUNT) cntClosest++;
-                    traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, 0.0f, kTMax, stack, innerMin, h, iters, cntNodes, cntTris);
-                    isHit = h.t < kTMax;
-                }
-                const unsigned long long m = __ballot(isHit);
-                if (i < nTrace) { // the record is read again after the traversal rather than held in registers across it
-                    const float4 a0 = q.trace[i], a1 = q.trace[q.B + i], a2 = q.trace[2u * q.B + i], a3 = q.trace[3u * q.B + i];
-                    if (isHit) {
-                        const uint32_t k = nShade + lanePrefix(m);
-                        q.shade[k] = a0;
-                        q.shade[q.B + k] = a1;
-                        q.shade[2u * q.B + k] = make_float4(a2.x, a2.y, a2.z, h.t);
-                        q.shade[3u * q.B + k] = make_float4(a3.x, a3.y, a3.z, h.u);
-                        q.shade[4u * q.B + k] = make_float4(h.v, __uint_as_float(h.tri), 0.0f, 0.0f);
-                    } else {
-                        q.done[__float_as_uint(a1.w) & 0xFFFFu] = make_float4(fmaf(a2.x, miss.x, a3.x), fmaf(a2.y, miss.y, a3.y), fmaf(a2.z, miss.z, a3.z), 0.0f);
-                    }
-                }
-                nShade += static_cast<uint32_t>(__popcll(m));
-            }
+            streamClosest<COUNT>(nodes, tris, p.n_nodes, q, nTrace, nShade, miss, stack, innerMin, iters, cntNodes, cntTris, cntClosest); // stage C
         }
         // ---- this pass's samples join the running sums in sample order; after the last pass: average, quantise, store
         const bool last = s0 + nS >= p.spp;
