@@ -77,6 +77,11 @@ struct crt_ctx {
     uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
     uint32_t tuneXcdGroup = 16;
     uint32_t tuneBoostUnits = 512;
+    // most expensive 8x8 packets rendered as four 4x4 quarters (render_kernels.hip).  Off by default: on the C3 frame 256 split
+    // packets take primary rays only (mode 3) from 0.204 to 0.187 ms but the Lambert + shadow frame from 0.294 to 0.307 ms (the
+    // quarters start first, while the chip is full, and trace their shadow rays at a quarter of the lane efficiency); the
+    // rank-share latency at 8 ranks moves from 188 to 182 us only: a packet's chain of dependent steps is its slowest RAY's
+    uint32_t tuneSplitUnits = 0;
     uint32_t debugSkipUnits = 0;
     hipStream_t lastRenderStream = nullptr;
     bool haveLastRenderStream = false;
@@ -215,6 +220,7 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.tune_inner_min = c->tuneInnerMin;
     p.xcd_group = c->tuneXcdGroup;
     p.boost_units = c->tuneBoostUnits;
+    p.split_units = 0; // set in runRender once a launch order is in use
     p.debug_skip_units = c->debugSkipUnits;
     // LDS part of the per-lane stack: 16 entries x 64 lanes x 4 B = 4 KB per wavefront, so that LDS never limits the 7
     // wavefronts per SIMD the kernel's register budget allows (12 .. 20 entries measured alike, 24 costs 4 %); no ray of the
@@ -305,6 +311,7 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         }
         const bool usable = c->orderKey[slot] == key;
         p.unit_order = usable ? c->dUnitOrder[slot] : nullptr;
+        p.split_units = usable ? std::min(c->tuneSplitUnits, nUnits) : 0u;
         // Costs are measured (and sorted) twice in a row -- the first measurement ran under an unordered launch -- and then:
         // an unchanged view keeps its order for good; a view that keeps changing (a moving camera) measures again every
         // remeasure_every-th use of the slot.  Default 1: the order ages fast -- with a camera turning 0.01 degrees per frame
@@ -330,6 +337,8 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evRender[slot], 0));
     c->sortPending[slot] = false;
     c->slotStream[slot] = c->stream;
+    // split packets add their quarters' lifetimes into their cost slot: start from zero
+    if (p.unit_cost && p.split_units) HIP_TRY(c, hipMemsetAsync(p.unit_cost, 0, sizeof(uint32_t) * nUnits, c->stream));
     if (stats) HIP_TRY(c, hipEventRecord(c->evStart, c->stream));
     const int rc = crt::launchRender(p, counting, c->stream);
     if (rc != 0) return fail(c, CRT_EHIP, "render kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rc)));
@@ -684,6 +693,10 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
     }
     if (std::strcmp(name, "xcd_group") == 0 && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) {
         c->tuneXcdGroup = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "split_units") == 0 && value >= 0 && value <= 65536) {
+        c->tuneSplitUnits = static_cast<uint32_t>(value);
         return CRT_OK;
     }
     if (std::strcmp(name, "boost_units") == 0 && value >= 0) {

@@ -41,6 +41,8 @@ struct RenderParams {
     uint32_t stack_entries;      // per-lane stack entries kept in LDS; deeper ones go to the spill arena
     uint32_t debug_skip_units;   // diagnostics: with unit_order, the first N work units are not rendered
     uint32_t boost_units;        // with unit_order: the first boost_units (most expensive) work units run at raised priority
+    uint32_t split_units;        // with unit_order: the first split_units work units are rendered by FOUR wavefronts, one per 4x4
+                                 // quarter of the 8x8 packet (16 lanes each): the frame's critical path is its slowest packets
     uint32_t xcd_group;          // consecutive tiles of the list handed to one XCD before moving to the next (1..16, power of 2)
     // outputs (device pointers, nullable except rgba8)
     uint32_t* rgba8;

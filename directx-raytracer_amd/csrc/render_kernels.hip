@@ -894,13 +894,26 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
     const float* camRot = frame ? p.batch_rot[frame - 1u] : p.rot;
     uint32_t* outRgba8 = frame ? p.batch_rgba8[frame - 1u] : p.rgba8;
     uint32_t unit;
+    // Split packets: a frame lasts as long as its slowest packets (grazing rays: hundreds of dependent steps, and a
+    // wavefront serves its divergent lanes one group after the other), and the launch order already knows which they are.
+    // The split_units most expensive packets are therefore rendered by four wavefronts each, one per 4x4 quarter with 16
+    // live lanes: fewer rays share a wavefront's step sequence, so each quarter finishes sooner than the whole would, at the
+    // price of idle lanes in a few hundred of the 32 640 wavefronts.  Scheduling only: every ray is traced as before.
+    uint32_t quarter = 4u; // 4 = the whole 8x8 packet
     if (p.unit_order) {
-        unit = p.unit_order[b];
+        uint32_t pos = b;
+        if (b < 4u * p.split_units) {
+            pos = b >> 2;
+            quarter = b & 3u;
+        } else {
+            pos = b - 3u * p.split_units;
+        }
+        unit = p.unit_order[pos];
         // the few packets with the longest critical paths bound the frame time even when they start first: let them
         // issue ahead of the other resident wavefronts
-        if (b < p.boost_units) __builtin_amdgcn_s_setprio(3);
+        if (pos < p.boost_units) __builtin_amdgcn_s_setprio(3);
 #if CRT_DIAG
-        if (b < p.debug_skip_units) return; // drop the most expensive packets to see what bounds the frame
+        if (pos < p.debug_skip_units) return; // drop the most expensive packets to see what bounds the frame
 #endif
     } else {
         const uint32_t xcd = b & 7u, seq = b >> 3, i = seq >> 2;
@@ -925,14 +938,21 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
         tile_y = k / p.tiles_x;
     }
     if (!valid) {
-        if (p.unit_cost && frame == 0u && threadIdx.x == 0) p.unit_cost[unit] = 0;
+        if (p.unit_cost && frame == 0u && threadIdx.x == 0 && quarter >= 4u) p.unit_cost[unit] = 0;
         return;
     }
 
     const uint32_t tid = threadIdx.x, wave = unit & 3u, lane = tid & 63u;
-    const uint32_t lx = (wave & 1u) * 8u + (lane & 7u), ly = (wave >> 1) * 8u + (lane >> 3);
+    uint32_t lx = (wave & 1u) * 8u, ly = (wave >> 1) * 8u;
+    if (quarter < 4u) { // lanes 0..15 walk the 4x4 quarter, the others have nothing to do
+        lx += (quarter & 1u) * 4u + (lane & 3u);
+        ly += (quarter >> 1) * 4u + ((lane >> 2) & 3u);
+    } else {
+        lx += lane & 7u;
+        ly += lane >> 3;
+    }
     const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
-    const bool active = (px < p.width) & (py < p.height);
+    const bool active = (px < p.width) & (py < p.height) & ((quarter == 4u) | (lane < 16u));
 
     uint32_t cntNodes = 0, cntTris = 0, cntShadow = 0, cntClosest = 0;
 #if CRT_PROF
@@ -946,7 +966,7 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
         const float4* tris = reinterpret_cast<const float4*>(p.tris);
         Stack stack;
         stack.lds = s_stack + tid;
-        stack.spill = p.spill + ((static_cast<size_t>(frame) * p.units_per_frame + unit) * 64u + tid) * p.spill_stride;
+        stack.spill = p.spill + ((static_cast<size_t>(frame) * p.units_per_frame + unit) * 64u + (quarter < 4u ? quarter * 16u + tid : tid)) * p.spill_stride;
         stack.cap = static_cast<int>(p.stack_entries);
         stack.sp = 0;
 
@@ -993,7 +1013,12 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
     }
     // cost fed back to order the next frame = this wavefront's lifetime in 0.64 us units (constant 100 MHz clock): it
     // sees what an iteration count does not (distant, incoherent packets are slow per iteration: cache misses)
-    if (p.unit_cost && frame == 0u && threadIdx.x == 0) p.unit_cost[unit] = static_cast<uint32_t>((__builtin_amdgcn_s_memrealtime() - t_start) >> 6);
+    // (a split packet reports the sum of its quarters' lifetimes into its slot, which the host zeroes before a measuring launch)
+    if (p.unit_cost && frame == 0u && threadIdx.x == 0) {
+        const uint32_t life = static_cast<uint32_t>((__builtin_amdgcn_s_memrealtime() - t_start) >> 6);
+        if (quarter < 4u) atomicAdd(&p.unit_cost[unit], life);
+        else p.unit_cost[unit] = life;
+    }
 #if CRT_DIAG
     if (p.timeline && threadIdx.x == 0) {
         // wave lifetime on the constant 100 MHz clock, and which XCD ran it
@@ -1489,7 +1514,7 @@ int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream)
         if (counting) hipLaunchKernelGGL((pathKernel<true>), grid, block, lds, stream, p);
         else hipLaunchKernelGGL((pathKernel<false>), grid, block, lds, stream, p);
     } else {
-        const dim3 grid(n * 4u * (p.n_batch ? p.n_batch : 1u));
+        const dim3 grid((n * 4u + (p.unit_order ? 3u * p.split_units : 0u)) * (p.n_batch ? p.n_batch : 1u));
         const bool phong = p.mode >= 100u && p.phong_ks > 0.0f;
         if (counting && phong) hipLaunchKernelGGL((renderKernel<true, true>), grid, block, lds, stream, p);
         else if (counting) hipLaunchKernelGGL((renderKernel<true, false>), grid, block, lds, stream, p);
