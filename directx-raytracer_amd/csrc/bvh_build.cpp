@@ -397,6 +397,8 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
     out.shade.clear();
     out.maxDepth = 0;
     out.uvs.clear();
+    out.nTris = 0;
+    out.devTris = out.devShade = out.devUvs = nullptr;
     if (n == 0) return;
 
     std::vector<Box> primBox(n);
@@ -467,6 +469,7 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
         out.shade[i] = inShade[order[i]];
     }
     lap("reorder records");
+    out.nTris = static_cast<uint32_t>(out.tris.size());
     collapseBvh4(out);
     lap("collapse");
     std::vector<crt_bvh_uv> inUv;

@@ -26,6 +26,11 @@ struct Bvh {
     std::vector<crt_bvh_shade> shade;  // 48 B each, leaf order
     std::vector<crt_bvh_uv> uvs;       // 24 B each, leaf order; empty when no mesh has uvs
     uint32_t maxDepth = 0;
+    uint32_t nTris = 0;                // triangles; = tris.size() unless the leaf-ordered records exist on the device only:
+    // GPU builder: tris / shade / uvs already sit in HBM (hipMalloc'ed, + 64 bytes of slack); whoever takes the Bvh owns them
+    void* devTris = nullptr;
+    void* devShade = nullptr;
+    void* devUvs = nullptr;
 };
 
 // meshes in InstanceID order; triangle gid = running ordinal over meshes. Throws std::runtime_error on bad input.

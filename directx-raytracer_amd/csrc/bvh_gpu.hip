@@ -2,7 +2,10 @@
 // runs on the GPU at init (R/DXRTRenderer.cpp:548-806).  LBVH: 30-bit Morton codes of the quantised box centroids,
 // radix sort, Karras 2012 hierarchy, bottom-up exact box fitting, ranges of <= 4 triangles collapsed to leaves.
 // Specification = oracle/crt_oracle.c build_lbvh(); the two produce byte-identical trees (tests/test_gpu_parity.py).
-// The binary tree is copied back and collapsed to the 4-wide tree by the same host routine as the SAH path.
+// The meshes go up as they are (vertices, indices, normals, uvs: 18 MB for 1M triangles instead of 130 MB of flattened
+// records); triangle boxes and the leaf-ordered triangle / shading / uv records are produced on the device and STAY there
+// (the context adopts the buffers); only the binary nodes come back, for the host routine that collapses them to the 4-wide
+// tree and quantises it, shared with the SAH path.
 // Quality is below the SAH builder's (about +37 % node fetches, 2x triangle tests on the 1M-triangle frame): it is the
 // fast option (option "gpu_build"), not the default.
 #include "bvh_build.h"
@@ -203,15 +206,102 @@ __global__ __launch_bounds__(256) void emitKernel(const KNode* __restrict__ K, c
     out[rank[i]] = N;
 }
 
-__global__ __launch_bounds__(256) void reorderKernel(const unsigned long long* __restrict__ keys, uint32_t n, const crt_bvh_tri* __restrict__ inTri,
-                                                     const crt_bvh_shade* __restrict__ inShade, crt_bvh_tri* __restrict__ tris,
-                                                     crt_bvh_shade* __restrict__ shade)
+// One entry per mesh (plus a terminator holding the totals): where its triangles and vertices start in the concatenated arrays
+struct MeshEntry {
+    uint32_t triStart, vertStart, nVerts, material;
+    uint32_t hasNormals, hasUvs, pad0, pad1;
+};
+
+__device__ __forceinline__ uint32_t meshOf(const MeshEntry* __restrict__ table, uint32_t n_meshes, uint32_t g)
+{
+    uint32_t lo = 0, hi = n_meshes; // largest m with triStart[m] <= g (meshes without triangles are skipped by the <=)
+    while (hi - lo > 1u) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (table[mid].triStart <= g) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+__device__ __forceinline__ float minSel(float a, float b) { return a < b ? a : b; }
+__device__ __forceinline__ float maxSel(float a, float b) { return a > b ? a : b; }
+
+// per input triangle (global ordinal g): bounds and centroid, exactly as flattenMeshes computes them on the host
+__global__ __launch_bounds__(256) void triBoxKernel(const MeshEntry* __restrict__ table, uint32_t n_meshes, const float* __restrict__ xyz,
+                                                    const uint32_t* __restrict__ idx, uint32_t n, Box6* __restrict__ box, float* __restrict__ cent,
+                                                    int* __restrict__ badIndex)
+{
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g >= n) return;
+    const MeshEntry M = table[meshOf(table, n_meshes, g)];
+    const uint32_t i0 = idx[3 * static_cast<size_t>(g)], i1 = idx[3 * static_cast<size_t>(g) + 1], i2 = idx[3 * static_cast<size_t>(g) + 2];
+    Box6 b;
+    if (i0 >= M.nVerts || i1 >= M.nVerts || i2 >= M.nVerts) {
+        *badIndex = 1;
+        for (int k = 0; k < 3; k++) { b.mn[k] = 0.0f; b.mx[k] = 0.0f; cent[3 * static_cast<size_t>(g) + k] = 0.0f; }
+        box[g] = b;
+        return;
+    }
+    const float* A = xyz + 3 * static_cast<size_t>(M.vertStart + i0);
+    const float* B = xyz + 3 * static_cast<size_t>(M.vertStart + i1);
+    const float* C = xyz + 3 * static_cast<size_t>(M.vertStart + i2);
+    for (int k = 0; k < 3; k++) {
+        b.mn[k] = minSel(minSel(A[k], B[k]), C[k]);
+        b.mx[k] = maxSel(maxSel(A[k], B[k]), C[k]);
+        cent[3 * static_cast<size_t>(g) + k] = (b.mn[k] + b.mx[k]) * 0.5f;
+    }
+    box[g] = b;
+}
+
+// leaf position i <- input triangle keys[i] & 0xFFFFFFFF: the 48-byte triangle record, the shading record and (when any
+// mesh has them) the uv record, written straight from the mesh arrays
+__global__ __launch_bounds__(256) void gatherKernel(const unsigned long long* __restrict__ keys, uint32_t n, const MeshEntry* __restrict__ table,
+                                                    uint32_t n_meshes, const float* __restrict__ xyz, const uint32_t* __restrict__ idx,
+                                                    const float* __restrict__ normals, const float* __restrict__ uvsIn, crt_bvh_tri* __restrict__ tris,
+                                                    crt_bvh_shade* __restrict__ shade, crt_bvh_uv* __restrict__ uvs)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
-    const uint32_t src = static_cast<uint32_t>(keys[i] & 0xFFFFFFFFull);
-    tris[i] = inTri[src];
-    shade[i] = inShade[src];
+    const uint32_t g = static_cast<uint32_t>(keys[i] & 0xFFFFFFFFull);
+    const uint32_t m = meshOf(table, n_meshes, g);
+    const MeshEntry M = table[m];
+    const uint32_t v0 = M.vertStart + idx[3 * static_cast<size_t>(g)], v1 = M.vertStart + idx[3 * static_cast<size_t>(g) + 1],
+                   v2 = M.vertStart + idx[3 * static_cast<size_t>(g) + 2];
+    const float* A = xyz + 3 * static_cast<size_t>(v0);
+    const float* B = xyz + 3 * static_cast<size_t>(v1);
+    const float* C = xyz + 3 * static_cast<size_t>(v2);
+    crt_bvh_tri T;
+    for (int k = 0; k < 3; k++) {
+        T.v0[k] = A[k];
+        T.e1[k] = B[k] - A[k];
+        T.e2[k] = C[k] - A[k];
+    }
+    T.inst = m;
+    T.prim = g - M.triStart;
+    T.gid = g;
+    tris[i] = T;
+    crt_bvh_shade S;
+    for (int k = 0; k < 3; k++) { S.n0[k] = 0.0f; S.n1[k] = 0.0f; S.n2[k] = 0.0f; }
+    S.material = M.material;
+    S.pad[0] = 0; S.pad[1] = 0;
+    if (M.hasNormals) {
+        for (int k = 0; k < 3; k++) {
+            S.n0[k] = normals[3 * static_cast<size_t>(v0) + k];
+            S.n1[k] = normals[3 * static_cast<size_t>(v1) + k];
+            S.n2[k] = normals[3 * static_cast<size_t>(v2) + k];
+        }
+    }
+    shade[i] = S;
+    if (uvs) {
+        crt_bvh_uv U;
+        U.uv0[0] = U.uv0[1] = U.uv1[0] = U.uv1[1] = U.uv2[0] = U.uv2[1] = 0.0f;
+        if (M.hasUvs) {
+            U.uv0[0] = uvsIn[3 * static_cast<size_t>(v0)]; U.uv0[1] = uvsIn[3 * static_cast<size_t>(v0) + 1];
+            U.uv1[0] = uvsIn[3 * static_cast<size_t>(v1)]; U.uv1[1] = uvsIn[3 * static_cast<size_t>(v1) + 1];
+            U.uv2[0] = uvsIn[3 * static_cast<size_t>(v2)]; U.uv2[1] = uvsIn[3 * static_cast<size_t>(v2) + 1];
+        }
+        uvs[i] = U;
+    }
 }
 
 struct DevBuf {
@@ -221,6 +311,7 @@ struct DevBuf {
     DevBuf(const DevBuf&) = delete;
     DevBuf& operator=(const DevBuf&) = delete;
     template <class T> T* as() const { return static_cast<T*>(p); }
+    void* release() { void* q = p; p = nullptr; return q; } // ownership leaves (the context adopts the buffer)
 };
 
 } // namespace
@@ -236,32 +327,39 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
         std::fprintf(stderr, "[build] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t - tlast).count());
         tlast = t;
     };
-    std::vector<crt_bvh_tri> inTri;
-    std::vector<crt_bvh_shade> inShade;
-    std::vector<float> pboxCent; // per triangle: 6 floats box + 3 floats centroid (9 floats)
-    flattenMeshes(meshes, n_meshes, inTri, inShade, pboxCent);
-    const uint32_t n = static_cast<uint32_t>(inTri.size());
-    out.nodes.clear(); out.nodes4.clear(); out.tris.clear(); out.shade.clear();
-    out.maxDepth = 0; out.depth4 = 0;
-    out.uvs.clear();
-    std::vector<crt_bvh_uv> inUv;
-    flattenUvs(meshes, n_meshes, inUv);
+    out = Bvh();
     if (device_ms) *device_ms = 0.0;
-    if (n == 0) return;
-    lap("host flatten");
-
-    // split the interleaved host array into the two device arrays the kernels read
-    std::vector<Box6> hBox(n);
-    std::vector<float> hCent(3 * static_cast<size_t>(n));
-    for (uint32_t i = 0; i < n; i++) {
-        std::memcpy(&hBox[i], &pboxCent[9 * static_cast<size_t>(i)], sizeof(Box6));
-        std::memcpy(&hCent[3 * static_cast<size_t>(i)], &pboxCent[9 * static_cast<size_t>(i) + 6], 3 * sizeof(float));
+    uint64_t total = 0, totalVerts = 0;
+    bool anyNormals = false, anyUvs = false;
+    for (uint32_t m = 0; m < n_meshes; m++) {
+        if (meshes[m].n_triangles && (!meshes[m].xyz || !meshes[m].idx)) throw std::runtime_error("mesh with triangles but null vertex/index pointer");
+        total += meshes[m].n_triangles;
+        totalVerts += meshes[m].n_vertices;
+        anyNormals |= meshes[m].normals != nullptr && meshes[m].n_triangles > 0;
+        anyUvs |= meshes[m].uvs != nullptr && meshes[m].n_triangles > 0;
     }
-    out.tris.resize(n);
-    out.shade.resize(n);
+    if (total >= (1ull << 28)) throw std::runtime_error("too many triangles (limit 2^28 - 1)");
+    if (totalVerts >= (1ull << 32)) throw std::runtime_error("too many vertices");
+    const uint32_t n = static_cast<uint32_t>(total);
+    if (n == 0) return;
 
     if (n <= static_cast<uint32_t>(kLeafMax)) {
-        // one leaf, wrapped in a node whose right child is an empty leaf with the same box (as the SAH path does)
+        // a handful of triangles: one leaf, wrapped in a node whose right child is an empty leaf with the same box (as the SAH
+        // path does); nothing worth a kernel launch -- the host does it with the same rules
+        std::vector<crt_bvh_tri> inTri;
+        std::vector<crt_bvh_shade> inShade;
+        std::vector<float> pboxCent; // per triangle: 6 floats box + 3 floats centroid
+        flattenMeshes(meshes, n_meshes, inTri, inShade, pboxCent);
+        std::vector<crt_bvh_uv> inUv;
+        flattenUvs(meshes, n_meshes, inUv);
+        std::vector<Box6> hBox(n);
+        std::vector<float> hCent(3 * static_cast<size_t>(n));
+        for (uint32_t i = 0; i < n; i++) {
+            std::memcpy(&hBox[i], &pboxCent[9 * static_cast<size_t>(i)], sizeof(Box6));
+            std::memcpy(&hCent[3 * static_cast<size_t>(i)], &pboxCent[9 * static_cast<size_t>(i) + 6], 3 * sizeof(float));
+        }
+        out.tris.resize(n);
+        out.shade.resize(n);
         Box6 root = hBox[0];
         for (uint32_t i = 1; i < n; i++)
             for (int a = 0; a < 3; a++) {
@@ -275,7 +373,6 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
         N.right = ~static_cast<int32_t>(0);
         N.pad0 = N.pad1 = 0;
         out.nodes.push_back(N);
-        // keys sort by Morton code then ordinal; with <= 4 triangles do it on the host with the same rule
         std::vector<unsigned long long> keys(n);
         float lo[3], hi[3];
         for (int a = 0; a < 3; a++) { lo[a] = hCent[a]; hi[a] = hCent[a]; }
@@ -300,36 +397,69 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
             out.tris[i] = inTri[keys[i] & 0xFFFFFFFFull];
             out.shade[i] = inShade[keys[i] & 0xFFFFFFFFull];
         }
+        out.nTris = n;
         out.maxDepth = 1;
         collapseBvh4(out);
         reorderUvs(inUv, out);
         return;
     }
 
+    // ---- the meshes as they are, back to back
+    std::vector<MeshEntry> table(n_meshes + 1u);
+    std::vector<float> hXyz(3 * static_cast<size_t>(totalVerts)), hNormals, hUvs;
+    std::vector<uint32_t> hIdx(3 * static_cast<size_t>(n));
+    if (anyNormals) hNormals.assign(3 * static_cast<size_t>(totalVerts), 0.0f);
+    if (anyUvs) hUvs.assign(3 * static_cast<size_t>(totalVerts), 0.0f);
+    {
+        uint32_t t0 = 0, v0 = 0;
+        for (uint32_t m = 0; m < n_meshes; m++) {
+            const crt_mesh_view& M = meshes[m];
+            MeshEntry& E = table[m];
+            E.triStart = t0; E.vertStart = v0; E.nVerts = M.n_vertices; E.material = static_cast<uint32_t>(M.material_index);
+            E.hasNormals = M.normals ? 1u : 0u; E.hasUvs = M.uvs ? 1u : 0u; E.pad0 = E.pad1 = 0;
+            if (M.n_vertices) std::memcpy(&hXyz[3 * static_cast<size_t>(v0)], M.xyz, sizeof(float) * 3 * M.n_vertices);
+            if (M.n_triangles) std::memcpy(&hIdx[3 * static_cast<size_t>(t0)], M.idx, sizeof(uint32_t) * 3 * static_cast<size_t>(M.n_triangles));
+            if (M.normals && M.n_vertices) std::memcpy(&hNormals[3 * static_cast<size_t>(v0)], M.normals, sizeof(float) * 3 * M.n_vertices);
+            if (M.uvs && M.n_vertices) std::memcpy(&hUvs[3 * static_cast<size_t>(v0)], M.uvs, sizeof(float) * 3 * M.n_vertices);
+            t0 += M.n_triangles;
+            v0 += M.n_vertices;
+        }
+        MeshEntry& E = table[n_meshes];
+        E.triStart = t0; E.vertStart = v0; E.nVerts = 0; E.material = 0; E.hasNormals = E.hasUvs = E.pad0 = E.pad1 = 0;
+    }
+    lap("host concatenate");
+
     const uint32_t nInternal = n - 1;
+    DevBuf dTable(sizeof(MeshEntry) * table.size()), dXyz(sizeof(float) * hXyz.size()), dIdx(sizeof(uint32_t) * hIdx.size());
+    DevBuf dNormals(sizeof(float) * hNormals.size()), dUvsIn(sizeof(float) * hUvs.size()), dBad(sizeof(int));
     DevBuf dBox(sizeof(Box6) * n), dCent(sizeof(float) * 3 * n), dBounds(sizeof(int) * 6);
     DevBuf dKeysIn(sizeof(unsigned long long) * n), dKeys(sizeof(unsigned long long) * n);
     DevBuf dK(sizeof(KNode) * nInternal), dParI(sizeof(int) * nInternal), dParL(sizeof(int) * n);
     DevBuf dNodeBox(sizeof(Box6) * nInternal), dFlags(sizeof(unsigned int) * nInternal);
     DevBuf dKept(sizeof(uint32_t) * nInternal), dRank(sizeof(uint32_t) * nInternal);
-    DevBuf dInTri(sizeof(crt_bvh_tri) * n), dInShade(sizeof(crt_bvh_shade) * n), dTris(sizeof(crt_bvh_tri) * n), dShade(sizeof(crt_bvh_shade) * n);
+    // the records the kernels will traverse (+64 bytes of slack for speculative wide loads of the last record)
+    DevBuf dTris(sizeof(crt_bvh_tri) * n + 64), dShade(sizeof(crt_bvh_shade) * n + 64), dUvs(anyUvs ? sizeof(crt_bvh_uv) * n + 64 : 0);
     size_t sortBytes = 0, scanBytes = 0;
     GPU_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sortBytes, dKeysIn.as<unsigned long long>(), dKeys.as<unsigned long long>(), static_cast<int>(n), 0, 62, stream));
     GPU_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, dKept.as<uint32_t>(), dRank.as<uint32_t>(), static_cast<int>(nInternal), stream));
     DevBuf dTemp(sortBytes > scanBytes ? sortBytes : scanBytes);
 
-    GPU_TRY(hipMemcpyAsync(dBox.p, hBox.data(), sizeof(Box6) * n, hipMemcpyHostToDevice, stream));
-    GPU_TRY(hipMemcpyAsync(dCent.p, hCent.data(), sizeof(float) * 3 * n, hipMemcpyHostToDevice, stream));
-    GPU_TRY(hipMemcpyAsync(dInTri.p, inTri.data(), sizeof(crt_bvh_tri) * n, hipMemcpyHostToDevice, stream));
-    GPU_TRY(hipMemcpyAsync(dInShade.p, inShade.data(), sizeof(crt_bvh_shade) * n, hipMemcpyHostToDevice, stream));
-
+    GPU_TRY(hipMemcpyAsync(dTable.p, table.data(), sizeof(MeshEntry) * table.size(), hipMemcpyHostToDevice, stream));
+    GPU_TRY(hipMemcpyAsync(dXyz.p, hXyz.data(), sizeof(float) * hXyz.size(), hipMemcpyHostToDevice, stream));
+    GPU_TRY(hipMemcpyAsync(dIdx.p, hIdx.data(), sizeof(uint32_t) * hIdx.size(), hipMemcpyHostToDevice, stream));
+    if (anyNormals) GPU_TRY(hipMemcpyAsync(dNormals.p, hNormals.data(), sizeof(float) * hNormals.size(), hipMemcpyHostToDevice, stream));
+    if (anyUvs) GPU_TRY(hipMemcpyAsync(dUvsIn.p, hUvs.data(), sizeof(float) * hUvs.size(), hipMemcpyHostToDevice, stream));
+    GPU_TRY(hipMemsetAsync(dBad.p, 0, sizeof(int), stream));
     if (timing) { GPU_TRY(hipStreamSynchronize(stream)); }
-    lap("alloc + H2D inputs");
+    lap("alloc + H2D meshes");
+
     hipEvent_t e0, e1;
     GPU_TRY(hipEventCreate(&e0));
     GPU_TRY(hipEventCreate(&e1));
     GPU_TRY(hipEventRecord(e0, stream));
     const dim3 blk(256), grdN((n + 255) / 256), grdI((nInternal + 255) / 256);
+    hipLaunchKernelGGL(triBoxKernel, grdN, blk, 0, stream, dTable.as<MeshEntry>(), n_meshes, dXyz.as<float>(), dIdx.as<uint32_t>(), n, dBox.as<Box6>(),
+                       dCent.as<float>(), dBad.as<int>());
     hipLaunchKernelGGL(initBoundsKernel, dim3(1), dim3(64), 0, stream, dBounds.as<int>());
     hipLaunchKernelGGL(boundsKernel, grdN, blk, 0, stream, dCent.as<float>(), n, dBounds.as<int>());
     hipLaunchKernelGGL(mortonKernel, grdN, blk, 0, stream, dCent.as<float>(), n, dBounds.as<int>(), dKeysIn.as<unsigned long long>());
@@ -341,32 +471,38 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
     hipLaunchKernelGGL(keptKernel, grdI, blk, 0, stream, dK.as<KNode>(), nInternal, dKept.as<uint32_t>());
     GPU_TRY(hipcub::DeviceScan::ExclusiveSum(dTemp.p, scanBytes, dKept.as<uint32_t>(), dRank.as<uint32_t>(), static_cast<int>(nInternal), stream));
     uint32_t lastKept = 0, lastRank = 0;
+    int bad = 0;
     GPU_TRY(hipMemcpyAsync(&lastKept, dKept.as<uint32_t>() + (nInternal - 1), 4, hipMemcpyDeviceToHost, stream));
     GPU_TRY(hipMemcpyAsync(&lastRank, dRank.as<uint32_t>() + (nInternal - 1), 4, hipMemcpyDeviceToHost, stream));
+    GPU_TRY(hipMemcpyAsync(&bad, dBad.p, sizeof(int), hipMemcpyDeviceToHost, stream));
     GPU_TRY(hipStreamSynchronize(stream));
+    if (bad) {
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        throw std::runtime_error("triangle index out of range");
+    }
     const uint32_t nKept = lastKept + lastRank;
     DevBuf dNodes(sizeof(crt_bvh_node) * nKept);
     hipLaunchKernelGGL(emitKernel, grdI, blk, 0, stream, dK.as<KNode>(), dKept.as<uint32_t>(), dRank.as<uint32_t>(), dNodeBox.as<Box6>(), dBox.as<Box6>(),
                        dKeys.as<unsigned long long>(), nInternal, dNodes.as<crt_bvh_node>());
-    hipLaunchKernelGGL(reorderKernel, grdN, blk, 0, stream, dKeys.as<unsigned long long>(), n, dInTri.as<crt_bvh_tri>(), dInShade.as<crt_bvh_shade>(),
-                       dTris.as<crt_bvh_tri>(), dShade.as<crt_bvh_shade>());
+    hipLaunchKernelGGL(gatherKernel, grdN, blk, 0, stream, dKeys.as<unsigned long long>(), n, dTable.as<MeshEntry>(), n_meshes, dXyz.as<float>(),
+                       dIdx.as<uint32_t>(), dNormals.as<float>(), dUvsIn.as<float>(), dTris.as<crt_bvh_tri>(), dShade.as<crt_bvh_shade>(),
+                       anyUvs ? dUvs.as<crt_bvh_uv>() : nullptr);
     GPU_TRY(hipGetLastError());
     GPU_TRY(hipEventRecord(e1, stream));
     if (timing) { GPU_TRY(hipStreamSynchronize(stream)); }
     lap("device build");
     out.nodes.resize(nKept);
     GPU_TRY(hipMemcpyAsync(out.nodes.data(), dNodes.p, sizeof(crt_bvh_node) * nKept, hipMemcpyDeviceToHost, stream));
-    GPU_TRY(hipMemcpyAsync(out.tris.data(), dTris.p, sizeof(crt_bvh_tri) * n, hipMemcpyDeviceToHost, stream));
-    GPU_TRY(hipMemcpyAsync(out.shade.data(), dShade.p, sizeof(crt_bvh_shade) * n, hipMemcpyDeviceToHost, stream));
     GPU_TRY(hipStreamSynchronize(stream));
     float ms = 0.f;
     GPU_TRY(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (device_ms) *device_ms = ms;
-    lap("D2H nodes/tris/shade");
+    lap("D2H binary nodes");
 
-    // depth of the binary tree (levels of nodes + the leaf level), then the shared host collapse to the wide tree
+    // depth of the binary tree (levels of nodes + the leaf level), then the shared host collapse to the quantised wide tree
     {
         std::vector<std::pair<int32_t, uint32_t>> st;
         st.emplace_back(0, 0u);
@@ -382,9 +518,12 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
     }
     lap("host depth walk");
     collapseBvh4(out);
-    lap("host collapse");
-    reorderUvs(inUv, out);
-    lap("uv reorder");
+    lap("host collapse + quantise");
+    // the leaf-ordered records stay in HBM: the caller adopts the buffers (and copies them out only if someone asks)
+    out.nTris = n;
+    out.devTris = dTris.release();
+    out.devShade = dShade.release();
+    out.devUvs = anyUvs ? dUvs.release() : nullptr;
 }
 
 } // namespace crt

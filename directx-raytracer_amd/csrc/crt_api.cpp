@@ -192,7 +192,7 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.texels = static_cast<const unsigned char*>(c->dTexels);
     p.n_textures = c->nTextures;
     p.n_nodes = static_cast<uint32_t>(c->bvh.nodes4.size());
-    p.n_tris = static_cast<uint32_t>(c->bvh.tris.size());
+    p.n_tris = c->bvh.nTris;
     p.n_lights = c->nLights;
     p.n_mats = c->nMats;
     crt::copyBytes(p.pos, c->pos, sizeof(p.pos));
@@ -540,28 +540,48 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     } catch (const std::exception& ex) {
         return fail(c, CRT_EINVAL, "BVH build failed: %s", ex.what());
     }
+    // records the GPU builder left in HBM: adopted below, or released here if anything fails before that
+    struct DevRecords {
+        crt::Bvh& b;
+        ~DevRecords()
+        {
+            for (void** q : { &b.devTris, &b.devShade, &b.devUvs }) {
+                if (*q) (void)hipFree(*q);
+                *q = nullptr;
+            }
+        }
+    } pending{ built };
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipDeviceSynchronize()); // frames in flight on any stream the caller used still read the old scene's buffers
     freeScene(c); // from here on a failure leaves NO scene (haveScene = false): never the new host tree over old device buffers
-    std::swap(c->bvh, built);
+    std::swap(c->bvh, built); // (pending now guards whatever the OLD tree still pointed at: nothing)
     c->buildDeviceMs = deviceMs;
+    const bool recordsOnDevice = c->bvh.devTris != nullptr;
+    if (recordsOnDevice) { // built on the GPU: the leaf-ordered records are already in HBM; adopted before anything else can fail
+        c->dTris = c->bvh.devTris;
+        c->dShade = c->bvh.devShade;
+        c->dUvs = c->bvh.devUvs;
+        c->bvh.devTris = c->bvh.devShade = c->bvh.devUvs = nullptr;
+    }
     const size_t nb = sizeof(crt_bvh_node4q) * c->bvh.nodes4q.size(); // the quantised wide tree is what the kernels traverse
-    const size_t tb = sizeof(crt_bvh_tri) * c->bvh.tris.size();
-    const size_t sb = sizeof(crt_bvh_shade) * c->bvh.shade.size();
+    const size_t tb = sizeof(crt_bvh_tri) * c->bvh.nTris;
+    const size_t sb = sizeof(crt_bvh_shade) * c->bvh.nTris;
     // +64 bytes of slack so that a speculative wide load of the last record stays inside the allocation
     HIP_TRY(c, hipMalloc(&c->dNodes, nb + 128));
-    HIP_TRY(c, hipMalloc(&c->dTris, tb + 64));
-    HIP_TRY(c, hipMalloc(&c->dShade, sb + 64));
+    if (nb) HIP_TRY(c, hipMemcpy(c->dNodes, c->bvh.nodes4q.data(), nb, hipMemcpyHostToDevice));
+    if (!recordsOnDevice) {
+        HIP_TRY(c, hipMalloc(&c->dTris, tb + 64));
+        HIP_TRY(c, hipMalloc(&c->dShade, sb + 64));
+        if (tb) HIP_TRY(c, hipMemcpy(c->dTris, c->bvh.tris.data(), tb, hipMemcpyHostToDevice));
+        if (sb) HIP_TRY(c, hipMemcpy(c->dShade, c->bvh.shade.data(), sb, hipMemcpyHostToDevice));
+        if (!c->bvh.uvs.empty()) {
+            const size_t ub = sizeof(crt_bvh_uv) * c->bvh.uvs.size();
+            HIP_TRY(c, hipMalloc(&c->dUvs, ub));
+            HIP_TRY(c, hipMemcpy(c->dUvs, c->bvh.uvs.data(), ub, hipMemcpyHostToDevice));
+        }
+    }
     HIP_TRY(c, hipMalloc(&c->dLights, sizeof(crt_light) * (n_lights + 1)));
     HIP_TRY(c, hipMalloc(&c->dMats, sizeof(crt_material) * (n_materials + 1)));
-    if (nb) HIP_TRY(c, hipMemcpy(c->dNodes, c->bvh.nodes4q.data(), nb, hipMemcpyHostToDevice));
-    if (tb) HIP_TRY(c, hipMemcpy(c->dTris, c->bvh.tris.data(), tb, hipMemcpyHostToDevice));
-    if (sb) HIP_TRY(c, hipMemcpy(c->dShade, c->bvh.shade.data(), sb, hipMemcpyHostToDevice));
-    if (!c->bvh.uvs.empty()) {
-        const size_t ub = sizeof(crt_bvh_uv) * c->bvh.uvs.size();
-        HIP_TRY(c, hipMalloc(&c->dUvs, ub));
-        HIP_TRY(c, hipMemcpy(c->dUvs, c->bvh.uvs.data(), ub, hipMemcpyHostToDevice));
-    }
     if (n_lights) HIP_TRY(c, hipMemcpy(c->dLights, lights, sizeof(crt_light) * n_lights, hipMemcpyHostToDevice));
     if (n_materials) HIP_TRY(c, hipMemcpy(c->dMats, materials, sizeof(crt_material) * n_materials, hipMemcpyHostToDevice));
     c->nLights = n_lights;
@@ -614,8 +634,11 @@ int crt_set_textures(crt_ctx* c, const crt_texture* textures, uint32_t n)
 int crt_bvh_export_uv(const crt_ctx* c, crt_bvh_uv* uvs, int* has_uvs)
 {
     if (!c || !c->haveScene) return CRT_ESTATE;
-    if (has_uvs) *has_uvs = c->bvh.uvs.empty() ? 0 : 1;
-    if (uvs && !c->bvh.uvs.empty()) crt::copyBytes(uvs, c->bvh.uvs.data(), sizeof(crt_bvh_uv) * c->bvh.uvs.size());
+    if (has_uvs) *has_uvs = c->dUvs ? 1 : 0;
+    if (uvs && c->dUvs) { // (the host copy exists only for trees built on the host)
+        if (!c->bvh.uvs.empty()) crt::copyBytes(uvs, c->bvh.uvs.data(), sizeof(crt_bvh_uv) * c->bvh.uvs.size());
+        else if (hipMemcpy(uvs, c->dUvs, sizeof(crt_bvh_uv) * c->bvh.nTris, hipMemcpyDeviceToHost) != hipSuccess) return CRT_EHIP;
+    }
     return CRT_OK;
 }
 
@@ -922,7 +945,7 @@ int crt_bvh_info(const crt_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t
 {
     if (!c || !c->haveScene) return CRT_ESTATE;
     if (n_nodes) *n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
-    if (n_tris) *n_tris = static_cast<uint32_t>(c->bvh.tris.size());
+    if (n_tris) *n_tris = c->bvh.nTris;
     if (max_depth) *max_depth = c->bvh.maxDepth;
     return CRT_OK;
 }
@@ -985,8 +1008,16 @@ int crt_bvh_export(const crt_ctx* c, crt_bvh_node* nodes, crt_bvh_tri* tris, crt
 {
     if (!c || !c->haveScene) return CRT_ESTATE;
     if (nodes) crt::copyBytes(nodes, c->bvh.nodes.data(), sizeof(crt_bvh_node) * c->bvh.nodes.size());
-    if (tris) crt::copyBytes(tris, c->bvh.tris.data(), sizeof(crt_bvh_tri) * c->bvh.tris.size());
-    if (shade) crt::copyBytes(shade, c->bvh.shade.data(), sizeof(crt_bvh_shade) * c->bvh.shade.size());
+    // a tree built on the GPU keeps its leaf-ordered records in HBM only: copy them out of there
+    const bool onDevice = c->bvh.tris.empty() && c->bvh.nTris != 0;
+    if (tris) {
+        if (!onDevice) crt::copyBytes(tris, c->bvh.tris.data(), sizeof(crt_bvh_tri) * c->bvh.tris.size());
+        else if (hipMemcpy(tris, c->dTris, sizeof(crt_bvh_tri) * c->bvh.nTris, hipMemcpyDeviceToHost) != hipSuccess) return CRT_EHIP;
+    }
+    if (shade) {
+        if (!onDevice) crt::copyBytes(shade, c->bvh.shade.data(), sizeof(crt_bvh_shade) * c->bvh.shade.size());
+        else if (hipMemcpy(shade, c->dShade, sizeof(crt_bvh_shade) * c->bvh.nTris, hipMemcpyDeviceToHost) != hipSuccess) return CRT_EHIP;
+    }
     return CRT_OK;
 }
 
