@@ -7,6 +7,7 @@
 // renumbered to DFS pre-order at the end.
 #include "mem_util.h"
 #include "bvh_build.h"
+#include "bvh_wide.h"
 
 #include <atomic>
 #include <cmath>
@@ -399,6 +400,8 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
     out.uvs.clear();
     out.nTris = 0;
     out.devTris = out.devShade = out.devUvs = nullptr;
+    out.devNodes = out.devNodes4 = out.devNodes4q = nullptr;
+    out.nNodes = out.nNodes4 = 0;
     if (n == 0) return;
 
     std::vector<Box> primBox(n);
@@ -487,14 +490,6 @@ void collapseBvh4(Bvh& bvh)
     bvh.nodes4q.clear();
     bvh.depth4 = 0;
     if (bvh.nodes.empty()) return;
-    struct Slot { int32_t ref; Box box; };
-    auto slotsOf = [&](int32_t b, Slot& l, Slot& r) {
-        const crt_bvh_node& N = bvh.nodes[b];
-        l.ref = N.left;
-        r.ref = N.right;
-        l.box.mn[0] = N.lx0; l.box.mx[0] = N.lx1; l.box.mn[1] = N.ly0; l.box.mx[1] = N.ly1; l.box.mn[2] = N.lz0; l.box.mx[2] = N.lz1;
-        r.box.mn[0] = N.rx0; r.box.mx[0] = N.rx1; r.box.mn[1] = N.ry0; r.box.mx[1] = N.ry1; r.box.mn[2] = N.rz0; r.box.mx[2] = N.rz1;
-    };
     struct Work { int32_t binary; int32_t parent; int slot; uint32_t depth; }; // parent wide node / slot to patch
     std::vector<Work> work;
     work.push_back({ 0, -1, 0, 1 });
@@ -502,106 +497,23 @@ void collapseBvh4(Bvh& bvh)
     while (!work.empty()) {
         const Work w = work.back();
         work.pop_back();
-        Slot sl[4];
-        int n = 2;
-        slotsOf(w.binary, sl[0], sl[1]);
-        while (n < 4) {
-            int best = -1;
-            float bestArea = -1.0f;
-            for (int i = 0; i < n; i++) {
-                if (sl[i].ref < 0) continue;
-                const float a = sl[i].box.halfArea();
-                if (a > bestArea) { bestArea = a; best = i; }
-            }
-            if (best < 0) break;
-            Slot l, r;
-            slotsOf(sl[best].ref, l, r);
-            for (int i = n; i > best + 1; i--) sl[i] = sl[i - 1];
-            sl[best] = l;
-            sl[best + 1] = r;
-            n++;
-        }
+        WideSlot sl[4];
+        const int n = wideSlots(bvh.nodes.data(), w.binary, 0u, sl, nullptr); // the rule itself: bvh_wide.h
         const int32_t me = static_cast<int32_t>(bvh.nodes4.size());
         bvh.nodes4.emplace_back();
-        crt_bvh_node4& W = bvh.nodes4.back();
-        std::memset(&W, 0, sizeof(W));
-        for (int i = 0; i < 4; i++) {
-            if (i < n) {
-                W.minx[i] = sl[i].box.mn[0]; W.maxx[i] = sl[i].box.mx[0];
-                W.miny[i] = sl[i].box.mn[1]; W.maxy[i] = sl[i].box.mx[1];
-                W.minz[i] = sl[i].box.mn[2]; W.maxz[i] = sl[i].box.mx[2];
-                W.ref[i] = sl[i].ref; // leaf reference, or a binary index patched below when the child is emitted
-            } else { // unused slot: an inverted box no ray can enter, so the traversal needs no separate emptiness test
-                W.minx[i] = W.miny[i] = W.minz[i] = std::numeric_limits<float>::infinity();
-                W.maxx[i] = W.maxy[i] = W.maxz[i] = -std::numeric_limits<float>::infinity();
-                W.ref[i] = CRT_BVH_EMPTY;
-            }
-        }
+        fillWide(sl, n, bvh.nodes4.back()); // inner refs are binary indices until the child is emitted
         if (w.parent >= 0) bvh.nodes4[w.parent].ref[w.slot] = me;
         if (w.depth > bvh.depth4) bvh.depth4 = w.depth;
         // children must come out in slot order right after this node (pre-order): push them in reverse
         for (int i = n - 1; i >= 0; i--)
             if (sl[i].ref >= 0) work.push_back({ sl[i].ref, me, i, w.depth + 1 });
     }
+    bvh.nNodes = static_cast<uint32_t>(bvh.nodes.size());
+    bvh.nNodes4 = static_cast<uint32_t>(bvh.nodes4.size());
     bvh.nodes4q.resize(bvh.nodes4.size());
     const int64_t nq = static_cast<int64_t>(bvh.nodes4.size());
 #pragma omp parallel for schedule(static) if (nq > 65536)
     for (int64_t i = 0; i < nq; i++) quantizeNode4(bvh.nodes4[static_cast<size_t>(i)], bvh.nodes4q[static_cast<size_t>(i)]);
-}
-
-// Quantised nodes.  Per axis: lo / hi = the node's own extent over the children whose box is finite and ordered on that
-// axis; quantum s = (hi - lo) / 255 nudged up so that fma(255, s, lo) >= hi; a child's planes are the largest q with
-// fma(q, s, lo) <= min and the smallest q with fma(q, s, lo) >= max (the decode expression itself is what is checked, so
-// the decoded box contains the full-precision one whatever the rounding).  A child that is not finite on an axis spans
-// the whole node there (q = 0..255).  Extents beyond 3e38 are clamped (coordinates that large are not supported).
-// oracle/crt_oracle.c quantize_node4() is the same rule, expression for expression.
-namespace {
-inline float decodePlane(uint32_t q, float s, float lo) { return std::fmaf(static_cast<float>(q), s, lo); }
-}
-
-void quantizeNode4(const crt_bvh_node4& W, crt_bvh_node4q& Q)
-{
-    const float* mins[3] = { W.minx, W.miny, W.minz };
-    const float* maxs[3] = { W.maxx, W.maxy, W.maxz };
-    uint32_t qlo[3] = { 0, 0, 0 }, qhi[3] = { 0, 0, 0 };
-    for (int a = 0; a < 3; a++) {
-        float lo = std::numeric_limits<float>::infinity(), hi = -std::numeric_limits<float>::infinity();
-        bool valid[4];
-        for (int k = 0; k < 4; k++) {
-            const float mn = mins[a][k], mx = maxs[a][k];
-            valid[k] = W.ref[k] != CRT_BVH_EMPTY && std::isfinite(mn) && std::isfinite(mx) && mn <= mx;
-            if (valid[k]) {
-                lo = mn < lo ? mn : lo;
-                hi = mx > hi ? mx : hi;
-            }
-        }
-        if (!(lo <= hi)) lo = hi = 0.0f; // no finite child on this axis
-        float ext = hi - lo;
-        if (!(ext < 3.0e38f)) ext = 3.0e38f;
-        float s = (ext * (1.0f / 255.0f)) * 1.000001f;
-        if (!(s >= std::numeric_limits<float>::min())) s = std::numeric_limits<float>::min();
-        Q.lo[a] = lo;
-        Q.s[a] = s;
-        for (int k = 0; k < 4; k++) {
-            uint32_t l = 0, h = 255;
-            if (W.ref[k] == CRT_BVH_EMPTY) {
-                l = 255;
-                h = 0;
-            } else if (valid[k]) {
-                const float fl = (mins[a][k] - lo) / s, fh = (maxs[a][k] - lo) / s;
-                l = fl >= 255.0f ? 255u : (fl > 0.0f ? static_cast<uint32_t>(fl) : 0u);
-                while (l > 0 && decodePlane(l, s, lo) > mins[a][k]) l--;
-                h = fh >= 255.0f ? 255u : (fh > 0.0f ? static_cast<uint32_t>(fh) : 0u);
-                while (h < 255 && decodePlane(h, s, lo) < maxs[a][k]) h++;
-            }
-            qlo[a] |= l << (8 * k);
-            qhi[a] |= h << (8 * k);
-        }
-    }
-    Q.qlo_x = qlo[0]; Q.qhi_x = qhi[0];
-    Q.qlo_y = qlo[1]; Q.qhi_y = qhi[1];
-    Q.qlo_z = qlo[2]; Q.qhi_z = qhi[2];
-    for (int k = 0; k < 4; k++) Q.ref[k] = W.ref[k];
 }
 
 } // namespace crt

@@ -31,6 +31,12 @@ struct Bvh {
     void* devTris = nullptr;
     void* devShade = nullptr;
     void* devUvs = nullptr;
+    // ... and so do the trees: binary nodes, wide nodes, quantised wide nodes (nodes / nodes4 / nodes4q stay empty on the host;
+    // nNodes / nNodes4 hold the counts).  For a tree built on the host nNodes = nodes.size(), nNodes4 = nodes4.size().
+    void* devNodes = nullptr;
+    void* devNodes4 = nullptr;
+    void* devNodes4q = nullptr;
+    uint32_t nNodes = 0, nNodes4 = 0;
 };
 
 // meshes in InstanceID order; triangle gid = running ordinal over meshes. Throws std::runtime_error on bad input.
@@ -45,7 +51,6 @@ void flattenUvs(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<crt_
 void reorderUvs(const std::vector<crt_bvh_uv>& inUv, Bvh& bvh);
 // binary -> wide collapse (DESIGN.md "BVH4"); called by both builders
 void collapseBvh4(Bvh& bvh);
-// wide node -> 64-byte quantised node (DESIGN.md "Quantised nodes"); collapseBvh4 applies it to the whole tree
-void quantizeNode4(const crt_bvh_node4& W, crt_bvh_node4q& Q);
+// (the collapse and quantisation rules themselves: bvh_wide.h, shared with the GPU builder)
 
 } // namespace crt

@@ -9,6 +9,7 @@
 // Quality is below the SAH builder's (about +37 % node fetches, 2x triangle tests on the 1M-triangle frame): it is the
 // fast option (option "gpu_build"), not the default.
 #include "bvh_build.h"
+#include "bvh_wide.h"
 
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
@@ -304,6 +305,100 @@ __global__ __launch_bounds__(256) void gatherKernel(const unsigned long long* __
     }
 }
 
+// ---- binary -> 4-wide collapse + quantisation on the device (the rules: bvh_wide.h; the host routine collapseBvh4 gives the
+// same bytes).  Level by level from the root: every wide node of the level absorbs its binary nodes (wideSlots) and reserves
+// places for its inner children in the next level (one atomic per wavefront: a wave prefix sum inside).  The result must be
+// numbered in DFS pre-order like the host's: subtree sizes bottom-up, then ids top-down (id of child k = id of the parent
+// + 1 + sizes of the children before it), then every node is written -- full precision and quantised -- at its id.
+struct WideTmp {
+    crt_bvh_node4 W;     // inner refs = binary indices
+    uint32_t child[4];   // temporary index (level order) of the inner children, ~0u for leaf / empty slots
+};
+
+__device__ __forceinline__ uint32_t waveExclusiveSum(uint32_t v, uint32_t& total)
+{
+    uint32_t incl = v;
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t up = __shfl_up(incl, off, 64);
+        if ((threadIdx.x & 63u) >= static_cast<uint32_t>(off)) incl += up;
+    }
+    total = __shfl(incl, 63, 64);
+    return incl - v;
+}
+
+__global__ __launch_bounds__(256) void wideExpandKernel(const crt_bvh_node* __restrict__ nodes, const uint32_t* __restrict__ frontier /* {binary, depth} pairs */,
+                                                        uint32_t count, uint32_t base, uint32_t nextBase, WideTmp* __restrict__ tmp,
+                                                        uint32_t* __restrict__ nextFrontier, uint32_t* __restrict__ nextCount, uint32_t* __restrict__ maxDepth)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t inner = 0;
+    WideSlot sl[4];
+    int n = 0;
+    if (i < count) {
+        uint32_t deep = 0;
+        n = wideSlots(nodes, static_cast<int32_t>(frontier[2u * i]), frontier[2u * i + 1u], sl, &deep);
+        atomicMax(maxDepth, deep);
+        for (int k = 0; k < n; k++) inner += sl[k].ref >= 0 ? 1u : 0u;
+    }
+    uint32_t total = 0;
+    const uint32_t before = waveExclusiveSum(inner, total);
+    uint32_t waveBase = 0;
+    if ((threadIdx.x & 63u) == 0u && total) waveBase = atomicAdd(nextCount, total);
+    waveBase = __shfl(waveBase, 0, 64);
+    if (i >= count) return;
+    WideTmp& T = tmp[base + i];
+    fillWide(sl, n, T.W);
+    uint32_t at = waveBase + before;
+    for (int k = 0; k < 4; k++) {
+        T.child[k] = ~0u;
+        if (k < n && sl[k].ref >= 0) {
+            nextFrontier[2u * at] = static_cast<uint32_t>(sl[k].ref);
+            nextFrontier[2u * at + 1u] = sl[k].depth;
+            T.child[k] = nextBase + at;
+            at++;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wideSizeKernel(const WideTmp* __restrict__ tmp, uint32_t base, uint32_t count, uint32_t* __restrict__ size)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const WideTmp& T = tmp[base + i];
+    uint32_t s = 1;
+    for (int k = 0; k < 4; k++)
+        if (T.child[k] != ~0u) s += size[T.child[k]];
+    size[base + i] = s;
+}
+
+__global__ __launch_bounds__(256) void wideIdKernel(const WideTmp* __restrict__ tmp, uint32_t base, uint32_t count, const uint32_t* __restrict__ size,
+                                                    uint32_t* __restrict__ id)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= count) return;
+    const WideTmp& T = tmp[base + i];
+    uint32_t run = id[base + i] + 1u; // (the root's id is set to 0 by the host)
+    for (int k = 0; k < 4; k++)
+        if (T.child[k] != ~0u) {
+            id[T.child[k]] = run;
+            run += size[T.child[k]];
+        }
+}
+
+__global__ __launch_bounds__(256) void wideEmitKernel(const WideTmp* __restrict__ tmp, uint32_t total, const uint32_t* __restrict__ id,
+                                                      crt_bvh_node4* __restrict__ nodes4, crt_bvh_node4q* __restrict__ nodes4q)
+{
+    const uint32_t t = blockIdx.x * 256u + threadIdx.x;
+    if (t >= total) return;
+    crt_bvh_node4 W = tmp[t].W;
+    for (int k = 0; k < 4; k++)
+        if (tmp[t].child[k] != ~0u) W.ref[k] = static_cast<int32_t>(id[tmp[t].child[k]]);
+    nodes4[id[t]] = W;
+    crt_bvh_node4q Q;
+    quantizeNode4(W, Q);
+    nodes4q[id[t]] = Q;
+}
+
 struct DevBuf {
     void* p = nullptr;
     explicit DevBuf(size_t bytes) { GPU_TRY(hipMalloc(&p, bytes ? bytes : 16)); }
@@ -489,36 +584,61 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
                        dIdx.as<uint32_t>(), dNormals.as<float>(), dUvsIn.as<float>(), dTris.as<crt_bvh_tri>(), dShade.as<crt_bvh_shade>(),
                        anyUvs ? dUvs.as<crt_bvh_uv>() : nullptr);
     GPU_TRY(hipGetLastError());
-    GPU_TRY(hipEventRecord(e1, stream));
     if (timing) { GPU_TRY(hipStreamSynchronize(stream)); }
     lap("device build");
-    out.nodes.resize(nKept);
-    GPU_TRY(hipMemcpyAsync(out.nodes.data(), dNodes.p, sizeof(crt_bvh_node) * nKept, hipMemcpyDeviceToHost, stream));
+    // ---- collapse to the 4-wide tree and quantise, still on the device
+    DevBuf dTmp(sizeof(WideTmp) * nKept), dSize(sizeof(uint32_t) * nKept), dId(sizeof(uint32_t) * nKept);
+    DevBuf dFrontA(sizeof(uint32_t) * 2 * nKept), dFrontB(sizeof(uint32_t) * 2 * nKept), dScalars(sizeof(uint32_t) * 2); // [0] next count, [1] max depth
+    std::vector<std::pair<uint32_t, uint32_t>> levels; // {first temporary index, count}
+    {
+        const uint32_t rootEntry[2] = { 0u, 0u };
+        GPU_TRY(hipMemcpyAsync(dFrontA.p, rootEntry, sizeof(rootEntry), hipMemcpyHostToDevice, stream));
+        GPU_TRY(hipMemsetAsync(dScalars.p, 0, sizeof(uint32_t) * 2, stream));
+        uint32_t base = 0, count = 1;
+        uint32_t* cur = dFrontA.as<uint32_t>();
+        uint32_t* nxt = dFrontB.as<uint32_t>();
+        while (count) {
+            if (static_cast<uint64_t>(base) + count > nKept) throw std::runtime_error("wide collapse: more wide nodes than binary nodes");
+            levels.emplace_back(base, count);
+            GPU_TRY(hipMemsetAsync(dScalars.p, 0, sizeof(uint32_t), stream));
+            hipLaunchKernelGGL(wideExpandKernel, dim3((count + 255) / 256), blk, 0, stream, dNodes.as<crt_bvh_node>(), cur, count, base, base + count,
+                               dTmp.as<WideTmp>(), nxt, dScalars.as<uint32_t>(), dScalars.as<uint32_t>() + 1);
+            uint32_t nextCount = 0;
+            GPU_TRY(hipMemcpyAsync(&nextCount, dScalars.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+            GPU_TRY(hipStreamSynchronize(stream));
+            base += count;
+            count = nextCount;
+            std::swap(cur, nxt);
+        }
+    }
+    const uint32_t nWide = levels.back().first + levels.back().second;
+    for (size_t L = levels.size(); L-- > 0;)
+        hipLaunchKernelGGL(wideSizeKernel, dim3((levels[L].second + 255) / 256), blk, 0, stream, dTmp.as<WideTmp>(), levels[L].first, levels[L].second, dSize.as<uint32_t>());
+    GPU_TRY(hipMemsetAsync(dId.p, 0, sizeof(uint32_t), stream)); // the root's id
+    for (size_t L = 0; L < levels.size(); L++)
+        hipLaunchKernelGGL(wideIdKernel, dim3((levels[L].second + 255) / 256), blk, 0, stream, dTmp.as<WideTmp>(), levels[L].first, levels[L].second, dSize.as<uint32_t>(),
+                           dId.as<uint32_t>());
+    DevBuf dNodes4(sizeof(crt_bvh_node4) * nWide), dNodes4q(sizeof(crt_bvh_node4q) * nWide + 128);
+    hipLaunchKernelGGL(wideEmitKernel, dim3((nWide + 255) / 256), blk, 0, stream, dTmp.as<WideTmp>(), nWide, dId.as<uint32_t>(), dNodes4.as<crt_bvh_node4>(),
+                       dNodes4q.as<crt_bvh_node4q>());
+    GPU_TRY(hipGetLastError());
+    uint32_t maxDepth = 0;
+    GPU_TRY(hipMemcpyAsync(&maxDepth, dScalars.as<uint32_t>() + 1, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+    GPU_TRY(hipEventRecord(e1, stream));
     GPU_TRY(hipStreamSynchronize(stream));
     float ms = 0.f;
     GPU_TRY(hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
     if (device_ms) *device_ms = ms;
-    lap("D2H binary nodes");
-
-    // depth of the binary tree (levels of nodes + the leaf level), then the shared host collapse to the quantised wide tree
-    {
-        std::vector<std::pair<int32_t, uint32_t>> st;
-        st.emplace_back(0, 0u);
-        uint32_t deepest = 1;
-        while (!st.empty()) {
-            const auto [idx, d] = st.back();
-            st.pop_back();
-            if (d + 1 > deepest) deepest = d + 1;
-            if (out.nodes[idx].left >= 0) st.emplace_back(out.nodes[idx].left, d + 1);
-            if (out.nodes[idx].right >= 0) st.emplace_back(out.nodes[idx].right, d + 1);
-        }
-        out.maxDepth = deepest;
-    }
-    lap("host depth walk");
-    collapseBvh4(out);
-    lap("host collapse + quantise");
+    lap("device collapse + quantise");
+    out.maxDepth = maxDepth;
+    out.depth4 = static_cast<uint32_t>(levels.size());
+    out.nNodes = nKept;
+    out.nNodes4 = nWide;
+    out.devNodes = dNodes.release();
+    out.devNodes4 = dNodes4.release();
+    out.devNodes4q = dNodes4q.release();
     // the leaf-ordered records stay in HBM: the caller adopts the buffers (and copies them out only if someone asks)
     out.nTris = n;
     out.devTris = dTris.release();

@@ -5,6 +5,7 @@
 #include "../../include/crt_hip.h"
 
 #include "bvh_build.h"
+#include "bvh_wide.h"
 #include "render_kernels.h"
 #include "scene.h"
 
@@ -49,7 +50,9 @@ struct crt_ctx {
     std::string error;
 
     crt::Bvh bvh; // host copy of what sits in HBM
-    void* dNodes = nullptr;
+    void* dNodes = nullptr;     // quantised wide nodes: what the kernels traverse
+    void* dBinNodes = nullptr;  // gpu_build only: the binary tree and the full-precision wide tree as the builder left them in
+    void* dWideNodes = nullptr; // HBM (no host copy exists; crt_bvh_export* read them back)
     void* dTris = nullptr;
     void* dShade = nullptr;
     void* dLights = nullptr;
@@ -158,7 +161,7 @@ int fail(crt_ctx* ctx, int code, const char* fmt, ...)
 
 void freeScene(crt_ctx* c)
 {
-    void** ptrs[] = { &c->dNodes, &c->dTris, &c->dShade, &c->dLights, &c->dMats, &c->dUvs };
+    void** ptrs[] = { &c->dNodes, &c->dBinNodes, &c->dWideNodes, &c->dTris, &c->dShade, &c->dLights, &c->dMats, &c->dUvs };
     for (void** p : ptrs) {
         if (*p) (void)hipFree(*p);
         *p = nullptr;
@@ -191,7 +194,7 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.textures = c->dTextures;
     p.texels = static_cast<const unsigned char*>(c->dTexels);
     p.n_textures = c->nTextures;
-    p.n_nodes = static_cast<uint32_t>(c->bvh.nodes4.size());
+    p.n_nodes = c->bvh.nNodes4;
     p.n_tris = c->bvh.nTris;
     p.n_lights = c->nLights;
     p.n_mats = c->nMats;
@@ -545,7 +548,7 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
         crt::Bvh& b;
         ~DevRecords()
         {
-            for (void** q : { &b.devTris, &b.devShade, &b.devUvs }) {
+            for (void** q : { &b.devTris, &b.devShade, &b.devUvs, &b.devNodes, &b.devNodes4, &b.devNodes4q }) {
                 if (*q) (void)hipFree(*q);
                 *q = nullptr;
             }
@@ -561,14 +564,19 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
         c->dTris = c->bvh.devTris;
         c->dShade = c->bvh.devShade;
         c->dUvs = c->bvh.devUvs;
-        c->bvh.devTris = c->bvh.devShade = c->bvh.devUvs = nullptr;
+        c->dNodes = c->bvh.devNodes4q;
+        c->dBinNodes = c->bvh.devNodes;
+        c->dWideNodes = c->bvh.devNodes4;
+        c->bvh.devTris = c->bvh.devShade = c->bvh.devUvs = c->bvh.devNodes = c->bvh.devNodes4 = c->bvh.devNodes4q = nullptr;
     }
     const size_t nb = sizeof(crt_bvh_node4q) * c->bvh.nodes4q.size(); // the quantised wide tree is what the kernels traverse
     const size_t tb = sizeof(crt_bvh_tri) * c->bvh.nTris;
     const size_t sb = sizeof(crt_bvh_shade) * c->bvh.nTris;
     // +64 bytes of slack so that a speculative wide load of the last record stays inside the allocation
-    HIP_TRY(c, hipMalloc(&c->dNodes, nb + 128));
-    if (nb) HIP_TRY(c, hipMemcpy(c->dNodes, c->bvh.nodes4q.data(), nb, hipMemcpyHostToDevice));
+    if (!c->dNodes) { // (a tree collapsed on the device is already there)
+        HIP_TRY(c, hipMalloc(&c->dNodes, nb + 128));
+        if (nb) HIP_TRY(c, hipMemcpy(c->dNodes, c->bvh.nodes4q.data(), nb, hipMemcpyHostToDevice));
+    }
     if (!recordsOnDevice) {
         HIP_TRY(c, hipMalloc(&c->dTris, tb + 64));
         HIP_TRY(c, hipMalloc(&c->dShade, sb + 64));
@@ -944,7 +952,7 @@ int crt_untile_device(crt_ctx* c, uint32_t w, uint32_t h, uint32_t n_ranks, cons
 int crt_bvh_info(const crt_ctx* c, uint32_t* n_nodes, uint32_t* n_tris, uint32_t* max_depth)
 {
     if (!c || !c->haveScene) return CRT_ESTATE;
-    if (n_nodes) *n_nodes = static_cast<uint32_t>(c->bvh.nodes.size());
+    if (n_nodes) *n_nodes = c->bvh.nNodes;
     if (n_tris) *n_tris = c->bvh.nTris;
     if (max_depth) *max_depth = c->bvh.maxDepth;
     return CRT_OK;
@@ -961,7 +969,7 @@ int crt_build_stats(const crt_ctx* c, double* upload_ms, double* device_build_ms
 int crt_bvh_info4(const crt_ctx* c, uint32_t* n_nodes4, uint32_t* depth4)
 {
     if (!c || !c->haveScene) return CRT_ESTATE;
-    if (n_nodes4) *n_nodes4 = static_cast<uint32_t>(c->bvh.nodes4.size());
+    if (n_nodes4) *n_nodes4 = c->bvh.nNodes4;
     if (depth4) *depth4 = c->bvh.depth4;
     return CRT_OK;
 }
@@ -969,14 +977,20 @@ int crt_bvh_info4(const crt_ctx* c, uint32_t* n_nodes4, uint32_t* depth4)
 int crt_bvh_export4(const crt_ctx* c, crt_bvh_node4* nodes4)
 {
     if (!c || !c->haveScene) return CRT_ESTATE;
-    if (nodes4) crt::copyBytes(nodes4, c->bvh.nodes4.data(), sizeof(crt_bvh_node4) * c->bvh.nodes4.size());
+    if (nodes4) {
+        if (!c->dWideNodes) crt::copyBytes(nodes4, c->bvh.nodes4.data(), sizeof(crt_bvh_node4) * c->bvh.nodes4.size());
+        else if (hipMemcpy(nodes4, c->dWideNodes, sizeof(crt_bvh_node4) * c->bvh.nNodes4, hipMemcpyDeviceToHost) != hipSuccess) return CRT_EHIP;
+    }
     return CRT_OK;
 }
 
 int crt_bvh_export4q(const crt_ctx* c, crt_bvh_node4q* nodes4q)
 {
     if (!c || !c->haveScene) return CRT_ESTATE;
-    if (nodes4q) crt::copyBytes(nodes4q, c->bvh.nodes4q.data(), sizeof(crt_bvh_node4q) * c->bvh.nodes4q.size());
+    if (nodes4q) {
+        if (!c->dWideNodes) crt::copyBytes(nodes4q, c->bvh.nodes4q.data(), sizeof(crt_bvh_node4q) * c->bvh.nodes4q.size());
+        else if (hipMemcpy(nodes4q, c->dNodes, sizeof(crt_bvh_node4q) * c->bvh.nNodes4, hipMemcpyDeviceToHost) != hipSuccess) return CRT_EHIP;
+    }
     return CRT_OK;
 }
 
@@ -1007,7 +1021,10 @@ int crt_bvh_build_host4(const crt_mesh_view* meshes, uint32_t n_meshes, crt_bvh_
 int crt_bvh_export(const crt_ctx* c, crt_bvh_node* nodes, crt_bvh_tri* tris, crt_bvh_shade* shade)
 {
     if (!c || !c->haveScene) return CRT_ESTATE;
-    if (nodes) crt::copyBytes(nodes, c->bvh.nodes.data(), sizeof(crt_bvh_node) * c->bvh.nodes.size());
+    if (nodes) {
+        if (!c->dBinNodes) crt::copyBytes(nodes, c->bvh.nodes.data(), sizeof(crt_bvh_node) * c->bvh.nodes.size());
+        else if (hipMemcpy(nodes, c->dBinNodes, sizeof(crt_bvh_node) * c->bvh.nNodes, hipMemcpyDeviceToHost) != hipSuccess) return CRT_EHIP;
+    }
     // a tree built on the GPU keeps its leaf-ordered records in HBM only: copy them out of there
     const bool onDevice = c->bvh.tris.empty() && c->bvh.nTris != 0;
     if (tris) {
