@@ -13,6 +13,7 @@ struct ihipStream_t;
 namespace crt {
 
 constexpr int kLeafMax = 4;       // triangles per leaf
+constexpr int kLbvhLeafMax = 2;   // GPU LBVH: a Karras node over at most this many triangles becomes a leaf (oracle: LBVH_LEAF_MAX)
 constexpr int kMaxDepth = 32;     // leaves at depth <= kMaxDepth => traversal stack <= kMaxDepth entries
 constexpr int kBins = 16;
 constexpr float kTravCost = 1.0f; // SAH cost of an inner-node visit, in triangle tests

@@ -6,8 +6,9 @@
 // records); triangle boxes and the leaf-ordered triangle / shading / uv records are produced on the device and STAY there
 // (the context adopts the buffers); only the binary nodes come back, for the host routine that collapses them to the 4-wide
 // tree and quantises it, shared with the SAH path.
-// Quality is below the SAH builder's (about +37 % node fetches, 2x triangle tests on the 1M-triangle frame): it is the
-// fast option (option "gpu_build"), not the default.
+// Cubic Morton cells and leaves of at most 2 triangles (per-axis scaling and the SAH builder's 4-triangle leaves measured +36 %
+// node fetches and +94 % triangle tests against the SAH tree on the 1M-triangle frame; now +18 % / -13 %).  It is the fast
+// option (option "gpu_build": 16 ms against 350 ms at 1M triangles), not the default.
 #include "bvh_build.h"
 #include "bvh_wide.h"
 
@@ -84,12 +85,13 @@ __global__ __launch_bounds__(256) void mortonKernel(const float* __restrict__ ce
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
     uint32_t q[3];
+    float extm = 0.0f; // one cell size for all three axes (that of the longest extent): cubic cells
     for (int a = 0; a < 3; a++) {
-        const float lo = fromOrderedInt(bounds[a]), hi = fromOrderedInt(bounds[3 + a]);
-        const float ext = hi - lo;
-        const float scale = ext > 0.0f ? 1024.0f / ext : 0.0f;
-        q[a] = quant10((cent[3 * static_cast<size_t>(i) + a] - lo) * scale);
+        const float ext = fromOrderedInt(bounds[3 + a]) - fromOrderedInt(bounds[a]);
+        if (ext > extm) extm = ext;
     }
+    const float scale = extm > 0.0f ? 1024.0f / extm : 0.0f;
+    for (int a = 0; a < 3; a++) q[a] = quant10((cent[3 * static_cast<size_t>(i) + a] - fromOrderedInt(bounds[a])) * scale);
     const uint32_t code = (expandBits10(q[0]) << 2) | (expandBits10(q[1]) << 1) | expandBits10(q[2]);
     keys[i] = (static_cast<unsigned long long>(code) << 32) | i;
 }
@@ -175,7 +177,7 @@ __global__ __launch_bounds__(256) void fitKernel(const KNode* __restrict__ K, co
 __global__ __launch_bounds__(256) void keptKernel(const KNode* __restrict__ K, uint32_t nInternal, uint32_t* __restrict__ kept)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < nInternal) kept[i] = (K[i].hi - K[i].lo + 1u > static_cast<uint32_t>(kLeafMax)) ? 1u : 0u;
+    if (i < nInternal) kept[i] = (K[i].hi - K[i].lo + 1u > static_cast<uint32_t>(kLbvhLeafMax)) ? 1u : 0u;
 }
 
 __device__ __forceinline__ int leafRefDev(uint32_t first, uint32_t count) { return ~static_cast<int>((first << 3) | count); }
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void emitKernel(const KNode* __restrict__ K, c
         } else {
             b[c] = nodeBox[ch];
             const uint32_t cnt = K[ch].hi - K[ch].lo + 1u;
-            ref[c] = cnt <= static_cast<uint32_t>(kLeafMax) ? leafRefDev(K[ch].lo, cnt) : static_cast<int>(rank[ch]);
+            ref[c] = cnt <= static_cast<uint32_t>(kLbvhLeafMax) ? leafRefDev(K[ch].lo, cnt) : static_cast<int>(rank[ch]);
         }
     }
     crt_bvh_node N;
@@ -480,9 +482,14 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
         auto expand = [](uint32_t v) { v = (v * 0x00010001u) & 0xFF0000FFu; v = (v * 0x00000101u) & 0x0F00F00Fu; v = (v * 0x00000011u) & 0xC30C30C3u; v = (v * 0x00000005u) & 0x49249249u; return v; };
         for (uint32_t i = 0; i < n; i++) {
             uint32_t q[3];
+            float extm = 0.0f;
             for (int a = 0; a < 3; a++) {
                 const float ext = hi[a] - lo[a];
-                const float f = (hCent[3 * i + a] - lo[a]) * (ext > 0.0f ? 1024.0f / ext : 0.0f);
+                if (ext > extm) extm = ext;
+            }
+            const float scale = extm > 0.0f ? 1024.0f / extm : 0.0f;
+            for (int a = 0; a < 3; a++) {
+                const float f = (hCent[3 * i + a] - lo[a]) * scale;
                 q[a] = f >= 0.0f ? (f < 1024.0f ? static_cast<uint32_t>(f) : 1023u) : 0u;
             }
             keys[i] = (static_cast<unsigned long long>((expand(q[0]) << 2) | (expand(q[1]) << 1) | expand(q[2])) << 32) | i;
