@@ -241,5 +241,11 @@ def test_random_meshes_both_builders_agree(pkg, oracle):
         nodes4, depth4 = pkg.build_bvh4_host(meshes)
         assert nodes4.tobytes() == O.nodes4().tobytes() and depth4 == O.depth4 and md == O.max_depth
         assert len(tris) == n_tris and sorted(tris["gid"].tolist()) == list(range(n_tris)) and md <= 32
+        # the 64-byte quantised nodes: both restatements of the rule agree on every input (huge extents are clamped alike);
+        # containment / tightness hold wherever the coordinates stay below the documented 3e38 extent limit
+        q = pkg.quantize4(nodes4)
+        assert q.tobytes() == O.nodes4q().tobytes()
+        if all(np.abs(m["vertices"]).max(initial=0.0) <= 1e30 for m in meshes):
+            _check_quantised(nodes4, q)
 
     run()
