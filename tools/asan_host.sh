@@ -12,7 +12,7 @@ for f in scene scene_parser bvh_build crt_api renderer; do
       -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $f.cpp -o build/asan/$f.o
 done
 g++ -shared -o ../libcrt_hip_asan.so build/asan/{scene,scene_parser,bvh_build,crt_api,renderer}.o build/render_kernels.o build/bvh_gpu.o \
-    -L/opt/rocm/lib -lamdhip64 -fopenmp -fsanitize=address,undefined -Wl,-rpath,/opt/rocm/lib
+    -L/opt/rocm/lib -lamdhip64 -ldl -fopenmp -fsanitize=address,undefined -Wl,-rpath,/opt/rocm/lib
 cd "$ROOT"
 # libstdc++ is preloaded beside libasan so that the __cxa_throw interceptor resolves inside the python process
 LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libstdc++.so)" ASAN_OPTIONS=detect_leaks=0 \
