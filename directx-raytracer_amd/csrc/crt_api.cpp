@@ -131,6 +131,9 @@ struct crt_ctx {
     void* dDistFrame[kRing] = {};
     size_t stageBytes[kRing] = {}, gatherBytes[kRing] = {}, distFrameBytes[kRing] = {};
     uint32_t distSerial = 0;
+    hipEvent_t evDist[kRing] = {};       // end of the frame that last used a slot's staging / gathered / frame buffers
+    hipStream_t distStream[kRing] = {};  // and the stream it ran on
+    bool distPending[kRing] = {};
 
     // scratch frame buffers for the host-output path, grown on demand
     void* dFrame[5] = { nullptr, nullptr, nullptr, nullptr, nullptr };
@@ -461,6 +464,7 @@ void crt_destroy(crt_ctx* c)
         if (c->dStage[i]) (void)hipFree(c->dStage[i]);
         if (c->dGather[i]) (void)hipFree(c->dGather[i]);
         if (c->dDistFrame[i]) (void)hipFree(c->dDistFrame[i]);
+        if (c->evDist[i]) (void)hipEventDestroy(c->evDist[i]);
     }
     if (c->dCounters) (void)hipFree(c->dCounters);
     if (c->dTextures) (void)hipFree(c->dTextures);
@@ -1163,6 +1167,8 @@ int crt_render_frame_distributed(crt_ctx* c, uint32_t w, uint32_t h, void* d_rgb
         if ((rc = ensureBuffer(c, &c->dDistFrame[k], &c->distFrameBytes[k], static_cast<size_t>(w) * h * 4)) != CRT_OK) return rc;
         frame = c->dDistFrame[k];
     }
+    // the slot's previous frame (4 frames ago) may have been issued on another stream: order behind it on the GPU
+    if (c->distPending[k] && c->distStream[k] != c->stream) HIP_TRY(c, hipStreamWaitEvent(c->stream, c->evDist[k], 0));
     crt_frame_stats local;
     rc = crt_render_tiles_device(c, w, h, c->commRank, n, c->dStage[k], stats ? &local : nullptr);
     if (rc) return rc;
@@ -1171,6 +1177,10 @@ int crt_render_frame_distributed(crt_ctx* c, uint32_t w, uint32_t h, void* d_rgb
     rc = crt_untile_device(c, w, h, n, c->dGather[k], frame);
     if (rc) return rc;
     if (host_rgba8) HIP_TRY(c, hipMemcpyAsync(host_rgba8, frame, static_cast<size_t>(w) * h * 4, hipMemcpyDeviceToHost, c->stream));
+    if (!c->evDist[k]) HIP_TRY(c, hipEventCreateWithFlags(&c->evDist[k], hipEventDisableTiming));
+    HIP_TRY(c, hipEventRecord(c->evDist[k], c->stream));
+    c->distStream[k] = c->stream;
+    c->distPending[k] = true;
     if (stats || host_rgba8) HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (stats) {
         *stats = local; // kernel_ms and the counters describe this rank's tile launch

@@ -54,6 +54,18 @@ def test_null_and_state_errors(pkg):
     assert L.crt_scene_mesh_count(None) == 0
 
 
+def test_comm_entry_points_reject_bad_arguments_without_a_gpu(pkg):
+    """crt_comm_* (native RCCL gather): argument errors are return codes; RCCL is not even loaded for them"""
+    L = pkg.lib()
+    assert L.crt_comm_unique_id(None) == 1          # CRT_EINVAL
+    assert L.crt_comm_init(None, 0, 1, None) == 1
+    assert L.crt_comm_destroy(None) == 1
+    assert L.crt_comm_info(None, None, None) == 1
+    assert L.crt_render_frame_distributed(None, 64, 64, None, None, None) == 1
+    out = os.popen("ldd %s" % pkg.LIB_PATH).read()
+    assert "rccl" not in out.lower(), "RCCL must stay a run-time (dlopen) dependency"
+
+
 def test_product_does_not_reference_the_oracle():
     """The product path must not import, link or call anything under oracle/."""
     pkg_dir = os.path.join(ROOT, "directx-raytracer_amd")
