@@ -20,7 +20,7 @@ def main():
     import torch
     pkg = entry.load_package()
     scenes = importlib.import_module(entry.PKG_NAME + ".scenes")
-    sc = scenes.heightfield(n_lights=1) if a.scene == "heightfield" else scenes.icosphere_soup()
+    sc = {"heightfield": lambda: scenes.heightfield(n_lights=1), "heightfield5m": lambda: scenes.heightfield(n=1581, n_lights=1), "soup": scenes.icosphere_soup}[a.scene]()
     r = pkg.Renderer(0)
     r.upload(sc["meshes"], sc["lights"], sc["materials"])
     r.set_camera(sc["camera"]["position"], sc["camera"]["matrix"])
