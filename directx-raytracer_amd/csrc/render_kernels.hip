@@ -1070,12 +1070,13 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
 // accesses (record i of a queue = one float4 per plane at index i).  Per path the arithmetic -- RNG stream, radiance
 // updates, their order -- is the oracle's, so frames stay bit-exact; the sample average runs in sample order at the end.
 // Samples beyond `path_samples` are further passes of the same wavefront over the same scratch.
-constexpr uint32_t kShadePlanes = 5, kTracePlanes = 4;
+constexpr uint32_t kShadePlanes = 3, kTracePlanes = 2;
 
 struct PathScratch {
-    float4* shade;   // kShadePlanes x B: {o, rng} {d, id} {thr, t} {L, u} {v, tri, -, -}
-    float4* trace;   // kTracePlanes x B: {o, rng} {d, id} {thr, -} {L, -}
-    float4* done;    // B: final radiance of path (sample-in-pass * 256 + pixel-in-tile)
+    float4* shade;   // kShadePlanes x B: {o, rng} {d, id | bounce << 16} {t, u, v, tri}
+    float4* trace;   // kTracePlanes x B: {o, rng} {d, id | bounce << 16}
+    float4* done;    // B, by path id (sample-in-pass * tile pixels + pixel-in-tile): the path's radiance so far, final when it ends
+    float4* thr;     // B, by path id: its throughput (only the shade stage changes it; the queues carry the ray, not this)
     float4* accum;   // 256: running sum over the samples of earlier passes
     uint32_t B;
 };
@@ -1116,16 +1117,16 @@ __device__ __forceinline__ void streamClosest(const float4* __restrict__ nodes, 
             const bool retire = idle & have, isHit = retire & (h.t < kTMax);
             const unsigned long long mh = __ballot(isHit);
             if (retire) {
-                const float4 a0 = q.trace[my], a1 = q.trace[q.B + my], a2 = q.trace[2u * q.B + my], a3 = q.trace[3u * q.B + my];
+                const float4 a0 = q.trace[my], a1 = q.trace[q.B + my];
                 if (isHit) {
                     const uint32_t k = nShade + lanePrefix(mh);
                     q.shade[k] = a0;
                     q.shade[q.B + k] = a1;
-                    q.shade[2u * q.B + k] = make_float4(a2.x, a2.y, a2.z, h.t);
-                    q.shade[3u * q.B + k] = make_float4(a3.x, a3.y, a3.z, h.u);
-                    q.shade[4u * q.B + k] = make_float4(h.v, __uint_as_float(h.tri), 0.0f, 0.0f);
+                    q.shade[2u * q.B + k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
                 } else {
-                    q.done[__float_as_uint(a1.w) & 0xFFFFu] = make_float4(fmaf(a2.x, miss.x, a3.x), fmaf(a2.y, miss.y, a3.y), fmaf(a2.z, miss.z, a3.z), 0.0f);
+                    const uint32_t id = __float_as_uint(a1.w) & 0xFFFFu;
+                    const float4 a2 = q.thr[id], a3 = q.done[id];
+                    q.done[id] = make_float4(fmaf(a2.x, miss.x, a3.x), fmaf(a2.y, miss.y, a3.y), fmaf(a2.z, miss.z, a3.z), 0.0f);
                 }
             }
             nShade += static_cast<uint32_t>(__popcll(mh));
@@ -1190,9 +1191,9 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
             uint32_t rng = 0, idb = 0;
             bool goesOn = false;
             if (retire) {
-                const float4 a2 = q.shade[2u * q.B + my], a3 = q.shade[3u * q.B + my];
                 rng = __float_as_uint(q.shade[my].w);
                 idb = __float_as_uint(q.shade[q.B + my].w);
+                const float4 a2 = q.thr[idb & 0xFFFFu], a3 = q.done[idb & 0xFFFFu];
                 thr = f3(a2.x, a2.y, a2.z);
                 L = f3(a3.x, a3.y, a3.z);
                 goesOn = alive;
@@ -1216,8 +1217,11 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
                         goesOn = true;
                     }
                 }
-                if (thrMul > 0.0f) thr = f3(thr.x * albedo.x, thr.y * albedo.y, thr.z * albedo.z);
-                if (!goesOn) q.done[idb & 0xFFFFu] = make_float4(L.x, L.y, L.z, 0.0f);
+                if (thrMul > 0.0f) {
+                    thr = f3(thr.x * albedo.x, thr.y * albedo.y, thr.z * albedo.z);
+                    if (goesOn) q.thr[idb & 0xFFFFu] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+                }
+                q.done[idb & 0xFFFFu] = make_float4(L.x, L.y, L.z, 0.0f); // final if the path ends here, else the sum so far
                 have = false;
             }
             const unsigned long long mOn = __ballot(goesOn);
@@ -1225,8 +1229,6 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
                 const uint32_t k = nTrace + lanePrefix(mOn);
                 q.trace[k] = make_float4(Po.x, Po.y, Po.z, __uint_as_float(rng));
                 q.trace[q.B + k] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(idb + 0x10000u)); // next bounce
-                q.trace[2u * q.B + k] = make_float4(thr.x, thr.y, thr.z, 0.0f);
-                q.trace[3u * q.B + k] = make_float4(L.x, L.y, L.z, 0.0f);
             }
             nTrace += static_cast<uint32_t>(__popcll(mOn));
             // 3. fetch: the lanes without an entry take the next ones of the queue
@@ -1240,9 +1242,8 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
                 const Ray r = makeRay(f3(a0.x, a0.y, a0.z), f3(a1.x, a1.y, a1.z));
                 const uint32_t bounce = __float_as_uint(a1.w) >> 16;
                 Hit h;
-                h.t = q.shade[2u * q.B + idx].w; h.u = q.shade[3u * q.B + idx].w;
-                const float4 a4 = q.shade[4u * q.B + idx];
-                h.v = a4.x; h.tri = __float_as_uint(a4.y); h.gid = 0;
+                const float4 a4 = q.shade[2u * q.B + idx];
+                h.t = a4.x; h.u = a4.y; h.v = a4.z; h.tri = __float_as_uint(a4.w); h.gid = 0;
                 const Surface sf = surfaceAt(p, tris, r, h);
                 N = sf.N;
                 albedo = sf.albedo;
@@ -1361,7 +1362,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
         q.shade = base;
         q.trace = q.shade + static_cast<size_t>(kShadePlanes) * q.B;
         q.done = q.trace + static_cast<size_t>(kTracePlanes) * q.B;
-        q.accum = q.done + q.B;
+        q.thr = q.done + q.B;
+        q.accum = q.thr + q.B;
     }
     const F3 miss = f3(p.miss[0], p.miss[1], p.miss[2]);
     uint32_t cntNodes = 0, cntTris = 0, cntShadow = 0, cntClosest = 0, iters = 0;
@@ -1389,7 +1391,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
                     if (COUNT) cntClosest++;
                     traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, innerMin, h, iters, cntNodes, cntTris);
                     isHit = h.t < kTMax;
-                    if (!isHit) q.done[id] = make_float4(fmaf(1.0f, miss.x, 0.0f), fmaf(1.0f, miss.y, 0.0f), fmaf(1.0f, miss.z, 0.0f), 0.0f);
+                    // radiance so far: a miss ends the path with throughput (1) x miss colour; a hit starts from nothing, throughput 1
+                    q.done[id] = isHit ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(fmaf(1.0f, miss.x, 0.0f), fmaf(1.0f, miss.y, 0.0f), fmaf(1.0f, miss.z, 0.0f), 0.0f);
+                    if (isHit) q.thr[id] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
                     if (s0 + sl == 0u && frame == 0u) { // the hit outputs report sample 0's camera ray
                         const size_t pix = static_cast<size_t>(py) * p.width + px;
                         uint32_t inst = 0xFFFFFFFFu, prim = 0xFFFFFFFFu;
@@ -1408,9 +1412,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
                     const uint32_t i = nShade + lanePrefix(m);
                     q.shade[i] = make_float4(r.o.x, r.o.y, r.o.z, __uint_as_float(rng));
                     q.shade[q.B + i] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(id)); // bounce 0 in the upper half
-                    q.shade[2u * q.B + i] = make_float4(1.0f, 1.0f, 1.0f, h.t);
-                    q.shade[3u * q.B + i] = make_float4(0.0f, 0.0f, 0.0f, h.u);
-                    q.shade[4u * q.B + i] = make_float4(h.v, __uint_as_float(h.tri), 0.0f, 0.0f);
+                    q.shade[2u * q.B + i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
                 }
                 nShade += static_cast<uint32_t>(__popcll(m));
             }
@@ -1498,7 +1500,7 @@ uint32_t renderUnitCount(const RenderParams& p)
 size_t pathRegionBytes(uint32_t tile, uint32_t samples_per_pass)
 {
     const size_t pixels = static_cast<size_t>(tile) * tile, B = pixels * samples_per_pass;
-    return (kShadePlanes + kTracePlanes + 1u) * B * sizeof(float4) + pixels * sizeof(float4);
+    return (kShadePlanes + kTracePlanes + 2u) * B * sizeof(float4) + pixels * sizeof(float4); // queues + radiance + throughput, + cross-pass sums
 }
 uint32_t pathWorkgroupCount(const RenderParams& p) { return renderUnitCount(p) / (p.path_tile == 16u ? 4u : 1u) * (p.n_batch ? p.n_batch : 1u); }
 
