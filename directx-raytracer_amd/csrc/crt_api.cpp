@@ -1,6 +1,6 @@
 // C ABI of libcrt_hip.so (include/crt_hip.h): renderer context over the HIP runtime + scene-layer accessors.
 // Each entry point cites the reference member it replaces in the header.  No CPU fallback exists here: every
-// render path ends in launchRender() (render_kernels.hip).
+// render path ends in launchRender() (render_kernels.hip; mode 200: path_kernels.hip).
 #include "mem_util.h"
 #include "../../include/crt_hip.h"
 
@@ -76,7 +76,7 @@ struct crt_ctx {
     uint32_t pathSpp = 4, pathBounces = 3, pathSeed = 1234; // mode 200 (BASELINE.json configs[4]: 4 spp, 3 bounces)
     uint32_t phongKsPermille = 0, phongExp = 32;            // mode 100: specular term, off by default
     uint32_t tunePathTile = 0;     // mode 200 work split: 0 = default (8), 8 / 16 = pixel tile edge per workgroup
-    uint32_t tuneInnerMin = 32;    // wave scheduling threshold of the traversal loop (render_kernels.hip)
+    uint32_t tuneInnerMin = 32;    // wave scheduling threshold of the traversal loop (traversal.hip.h)
     uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
     uint32_t tuneXcdGroup = 16;
     uint32_t tuneBoostUnits = 512;
@@ -115,7 +115,7 @@ struct crt_ctx {
     hipStream_t sideStream = nullptr; // sorts the costs of frame f while later frames render
     hipEvent_t evRender[kRing] = {}, evSort[kRing] = {};
     unsigned long long* dCounters = nullptr;
-    int* dSpill[kRing] = {};          // traversal-stack spill arenas (render_kernels.hip Stack), one per ring slot
+    int* dSpill[kRing] = {};          // traversal-stack spill arenas (traversal.hip.h Stack), one per ring slot
     size_t spillBytes[kRing] = {};
     unsigned char* dPathScratch[kRing] = {}; // mode 200: queues of the wavefront-private path pipeline, one set per ring slot
     size_t pathScratchBytes[kRing] = {};

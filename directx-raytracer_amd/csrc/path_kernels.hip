@@ -1,0 +1,446 @@
+// HIP kernel for gfx950 (MI355X): mode 200, path tracing (BASELINE.json configs[4]) -- no counterpart in the reference, whose
+// closestHit shader only colours the primary hit (R/HLSL/ray_tracing_shaders.hlsl:78-169); specification: oracle trace_path.
+#include "shading.hip.h"
+
+namespace crt {
+namespace {
+
+// ---- mode 200: path tracing as a wavefront-private pipeline (oracle: trace_path; replaces the per-lane bounce loop, which
+// kept 22 % of the lanes busy: a lane whose path had ended idled until the longest path of its wavefront ended).
+//
+// One workgroup = one wavefront = one pixel tile x `path_samples` samples = B paths: by default an 8x8 packet x up to 16
+// samples (256 paths at 4 spp); option "path_tile" = 16 makes it a 16x16 macro tile x 4 samples (longer queues, fewer
+// workgroups: slower at both 1080p and 4K).  The wavefront
+// runs the whole pipeline for ITS paths by stages, 64 paths at a time, with two private queues in HBM scratch:
+//   stage A  camera rays of the tile (coherent 8x8 packets, octant-specialised scalar-fetch descent), closest hit;
+//            a miss finishes the path, a hit is appended to the shade queue;
+//   stage B  every entry of the shade queue: surface, material, direct light (any-hit shadow rays), next direction; a path
+//            that ends writes its radiance, one that goes on is appended to the trace queue;
+//   stage C  every entry of the trace queue: closest hit of the bounce ray; miss -> finished, hit -> shade queue; back to B.
+// Appending = wavefront ballot + prefix count (mbcnt) + a scalar running count: every stage works on dense 64-path
+// chunks, no atomics, no cross-wavefront traffic, no kernel boundary, and the queues are streamed with coalesced dwordx4
+// accesses (record i of a queue = one float4 per plane at index i).  Per path the arithmetic -- RNG stream, radiance
+// updates, their order -- is the oracle's, so frames stay bit-exact; the sample average runs in sample order at the end.
+// Samples beyond `path_samples` are further passes of the same wavefront over the same scratch.
+constexpr uint32_t kShadePlanes = 3, kTracePlanes = 2;
+
+struct PathScratch {
+    float4* shade;   // kShadePlanes x B: {o, rng} {d, id | bounce << 16} {t, u, v, tri}
+    float4* trace;   // kTracePlanes x B: {o, rng} {d, id | bounce << 16}
+    float4* done;    // B, by path id (sample-in-pass * tile pixels + pixel-in-tile): the path's radiance so far, final when it ends
+    float4* thr;     // B, by path id: its throughput (only the shade stage changes it; the queues carry the ray, not this)
+    float4* accum;   // 256: running sum over the samples of earlier passes
+    uint32_t B;
+};
+
+__device__ __forceinline__ uint32_t lanePrefix(unsigned long long m)
+{
+    return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(m >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(m), 0u));
+}
+
+// Stage C as a stream: the bounce rays of the trace queue are incoherent and their traversals differ a lot in length, so
+// a chunk-at-a-time loop leaves most lanes idle while the longest ray of each chunk finishes.  Here a lane that has finished
+// retires its ray (miss -> radiance written, hit -> appended to the shade queue) and takes the next entry of the queue,
+// as soon as at least `refillMin` lanes are idle: the wavefront stays full until the queue runs dry.  Every ray is still
+// traced by one lane in its own fixed order, so results and fetch counts are those of the chunked loop.
+#ifndef CRT_REFILL_MIN
+#define CRT_REFILL_MIN 16
+#endif
+template <bool COUNT>
+__device__ __forceinline__ void streamClosest(const float4* __restrict__ nodes, const float4* __restrict__ tris, uint32_t n_nodes,
+                                              const PathScratch& q, uint32_t nTrace, uint32_t& nShade, F3 miss, Stack& stack, int innerMin,
+                                              uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntClosest)
+{
+    constexpr int BLOCK = 64;
+    Ray r = makeRay(f3(0.0f, 0.0f, 0.0f), f3(0.0f, 0.0f, 1.0f));
+    Hit h;
+    h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
+    float tcull = kTMax * kCullPad;
+    int cur = kDone;
+    bool have = false;   // this lane holds a ray (being traced, or finished and not yet retired)
+    uint32_t my = 0;     // its index in the trace queue
+    uint32_t next = 0;   // wave-uniform: first queue entry not yet handed to a lane
+    const unsigned long long all = __ballot(true);
+    for (;;) {
+        const bool idle = cur == kDone;
+        const unsigned long long idleMask = __ballot(idle);
+        if (idleMask == all || (next < nTrace && static_cast<uint32_t>(__popcll(idleMask)) >= static_cast<uint32_t>(CRT_REFILL_MIN))) {
+            // retire the finished rays ...
+            const bool retire = idle & have, isHit = retire & (h.t < kTMax);
+            const unsigned long long mh = __ballot(isHit);
+            if (retire) {
+                const float4 a0 = q.trace[my], a1 = q.trace[q.B + my];
+                if (isHit) {
+                    const uint32_t k = nShade + lanePrefix(mh);
+                    q.shade[k] = a0;
+                    q.shade[q.B + k] = a1;
+                    q.shade[2u * q.B + k] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+                } else {
+                    const uint32_t id = __float_as_uint(a1.w) & 0xFFFFu;
+                    const float4 a2 = q.thr[id], a3 = q.done[id];
+                    q.done[id] = make_float4(fmaf(a2.x, miss.x, a3.x), fmaf(a2.y, miss.y, a3.y), fmaf(a2.z, miss.z, a3.z), 0.0f);
+                }
+            }
+            nShade += static_cast<uint32_t>(__popcll(mh));
+            // ... and hand the next queue entries to the idle lanes
+            const uint32_t idx = next + lanePrefix(idleMask);
+            if (idle) {
+                have = idx < nTrace;
+                if (have) {
+                    my = idx;
+                    const float4 a0 = q.trace[idx], a1 = q.trace[q.B + idx];
+                    r = makeRay(f3(a0.x, a0.y, a0.z), f3(a1.x, a1.y, a1.z));
+                    h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
+                    tcull = kTMax * kCullPad;
+                    stack.sp = 0;
+                    cur = n_nodes ? 0 : kDone;
+                    if (COUNT) cntClosest++;
+                }
+            }
+            next += static_cast<uint32_t>(__popcll(idleMask));
+            if (__ballot(have) == 0ull) break; // queue empty and every ray retired
+        }
+        closestIteration<COUNT, BLOCK, 8>(nodes, tris, r, 0.0f, tcull, stack, innerMin, h, cur, iters, cntNodes, cntTris);
+    }
+}
+
+// Stage B as a stream (same idea as streamClosest): the entries of the shade queue are shaded by whichever lane is free.
+// A lane's life with one entry: fetch (surface, material; mirror / glass / constant finish at once) -> for each light with a
+// positive cosine, in light order: one any-hit shadow ray, its contribution added when unoccluded (oracle: direct_light) ->
+// retire (radiance update, next direction drawn, appended to the trace queue or written out as finished).  Shadow rays end at
+// their first hit, so their traversals differ even more in length than the bounce rays': refilling keeps the wavefront full.
+template <bool COUNT>
+__device__ __forceinline__ void streamShade(const RenderParams& p, const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                            const PathScratch& q, uint32_t nShade, uint32_t& nTrace, Stack& stack, int innerMin,
+                                            uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
+{
+    constexpr int BLOCK = 64;
+    const LightRec* lights = reinterpret_cast<const LightRec*>(p.lights);
+    Ray sr = makeRay(f3(0.0f, 0.0f, 0.0f), f3(0.0f, 0.0f, 1.0f)); // the shadow ray in flight
+    float dist = 0.0f, tcull = 0.0f, kcur = 0.0f;                  // its length, cull bound, and the light's weight if it arrives
+    bool occluded = false;
+    int cur = kDone;
+    bool have = false, diffuse = false, tracing = false, alive = false;
+    float thrMul = 0.0f;  // 1: throughput *= albedo when the path goes on; -1: CONSTANT (radiance += throughput * albedo)
+    uint32_t my = 0, li = 0;
+    F3 Po = f3(0.f, 0.f, 0.f), N = f3(0.f, 0.f, 1.f), albedo = f3(0.f, 0.f, 0.f);
+    F3 aux = f3(0.f, 0.f, 0.f); // DIFFUSE: direct light gathered so far; REFLECTIVE / REFRACTIVE: the next direction
+    uint32_t next = 0;
+    const unsigned long long all = __ballot(true);
+    for (;;) {
+        const bool idle = cur == kDone;
+        const unsigned long long idleMask = __ballot(idle);
+        if (idleMask == all || (next < nShade && static_cast<uint32_t>(__popcll(idleMask)) >= static_cast<uint32_t>(CRT_REFILL_MIN))) {
+            // 1. a shadow ray has come back: its light counts unless something is in the way
+            if (idle & tracing) {
+                if (!occluded) aux = f3(fmaf(albedo.x, kcur, aux.x), fmaf(albedo.y, kcur, aux.y), fmaf(albedo.z, kcur, aux.z));
+                tracing = false;
+                li++;
+            }
+            // 2. retire: the entries whose lights are all done (or that never had any to ask)
+            const bool retire = idle & have & !(diffuse & (li < p.n_lights));
+            F3 thr = f3(0.f, 0.f, 0.f), L = f3(0.f, 0.f, 0.f), nd = f3(0.f, 0.f, 0.f);
+            uint32_t rng = 0, idb = 0;
+            bool goesOn = false;
+            if (retire) {
+                rng = __float_as_uint(q.shade[my].w);
+                idb = __float_as_uint(q.shade[q.B + my].w);
+                const float4 a2 = q.thr[idb & 0xFFFFu], a3 = q.done[idb & 0xFFFFu];
+                thr = f3(a2.x, a2.y, a2.z);
+                L = f3(a3.x, a3.y, a3.z);
+                goesOn = alive;
+                nd = aux;
+                if (thrMul < 0.0f) L = f3(fmaf(thr.x, albedo.x, L.x), fmaf(thr.y, albedo.y, L.y), fmaf(thr.z, albedo.z, L.z));
+                if (diffuse) {
+                    L = f3(fmaf(thr.x, aux.x, L.x), fmaf(thr.y, aux.y, L.y), fmaf(thr.z, aux.z, L.z));
+                    if ((idb >> 16) != p.max_bounces) {
+                        const float u1 = rngNext(rng), u2 = rngNext(rng);
+                        const float rr = sqrtf(u1), phi = 6.28318530717958648f * u2;
+                        const float lx = rr * sinContract(phi + 1.57079632679489662f), ly = rr * sinContract(phi), lz = sqrtf(fmaxf(0.0f, 1.0f - u1));
+                        const float sg = copysignf(1.0f, N.z);
+                        const float a = -1.0f / (sg + N.z);
+                        const float b = N.x * N.y * a;
+                        const F3 T = f3(1.0f + sg * N.x * N.x * a, sg * b, -sg * N.x);
+                        const F3 Bv = f3(b, sg + N.y * N.y * a, -N.y);
+                        const F3 d = f3(fmaf(lz, N.x, fmaf(ly, Bv.x, lx * T.x)), fmaf(lz, N.y, fmaf(ly, Bv.y, lx * T.y)),
+                                        fmaf(lz, N.z, fmaf(ly, Bv.z, lx * T.z)));
+                        nd = normalize3(d);
+                        thrMul = 1.0f;
+                        goesOn = true;
+                    }
+                }
+                if (thrMul > 0.0f) {
+                    thr = f3(thr.x * albedo.x, thr.y * albedo.y, thr.z * albedo.z);
+                    if (goesOn) q.thr[idb & 0xFFFFu] = make_float4(thr.x, thr.y, thr.z, 0.0f);
+                }
+                q.done[idb & 0xFFFFu] = make_float4(L.x, L.y, L.z, 0.0f); // final if the path ends here, else the sum so far
+                have = false;
+            }
+            const unsigned long long mOn = __ballot(goesOn);
+            if (goesOn) {
+                const uint32_t k = nTrace + lanePrefix(mOn);
+                q.trace[k] = make_float4(Po.x, Po.y, Po.z, __uint_as_float(rng));
+                q.trace[q.B + k] = make_float4(nd.x, nd.y, nd.z, __uint_as_float(idb + 0x10000u)); // next bounce
+            }
+            nTrace += static_cast<uint32_t>(__popcll(mOn));
+            // 3. fetch: the lanes without an entry take the next ones of the queue
+            const bool wantNew = idle & !have;
+            const unsigned long long mNew = __ballot(wantNew);
+            const uint32_t idx = next + lanePrefix(mNew);
+            if (wantNew && idx < nShade) {
+                have = true;
+                my = idx;
+                const float4 a0 = q.shade[idx], a1 = q.shade[q.B + idx];
+                const Ray r = makeRay(f3(a0.x, a0.y, a0.z), f3(a1.x, a1.y, a1.z));
+                const uint32_t bounce = __float_as_uint(a1.w) >> 16;
+                Hit h;
+                const float4 a4 = q.shade[2u * q.B + idx];
+                h.t = a4.x; h.u = a4.y; h.v = a4.z; h.tri = __float_as_uint(a4.w); h.gid = 0;
+                const Surface sf = surfaceAt(p, tris, r, h);
+                N = sf.N;
+                albedo = sf.albedo;
+                diffuse = false; alive = false; thrMul = 0.0f; li = 0;
+                aux = f3(0.0f, 0.0f, 0.0f);
+                Po = biasPoint(sf.P, sf.N, kShadowBias);
+                if (sf.mtype == 4u) { // CONSTANT
+                    thrMul = -1.0f;
+                } else if (sf.mtype == 2u) { // REFLECTIVE
+                    if (bounce != p.max_bounces) {
+                        const float k = 2.0f * dot3(r.d, sf.N);
+                        aux = normalize3(f3(fmaf(-k, sf.N.x, r.d.x), fmaf(-k, sf.N.y, r.d.y), fmaf(-k, sf.N.z, r.d.z)));
+                        thrMul = 1.0f;
+                        alive = true;
+                    }
+                } else if (sf.mtype == 3u) { // REFRACTIVE
+                    if (bounce != p.max_bounces) {
+                        const float eta = sf.entering ? 1.0f / sf.ior : sf.ior;
+                        const float cosi = -dot3(r.d, sf.N);
+                        const float k = 1.0f - eta * eta * (1.0f - cosi * cosi);
+                        F3 d;
+                        if (k < 0.0f) {
+                            const float m2 = 2.0f * dot3(r.d, sf.N);
+                            d = f3(fmaf(-m2, sf.N.x, r.d.x), fmaf(-m2, sf.N.y, r.d.y), fmaf(-m2, sf.N.z, r.d.z));
+                        } else {
+                            const float m2 = eta * cosi - sqrtf(k);
+                            d = f3(fmaf(m2, sf.N.x, eta * r.d.x), fmaf(m2, sf.N.y, eta * r.d.y), fmaf(m2, sf.N.z, eta * r.d.z));
+                            Po = biasPoint(sf.P, sf.N, -kShadowBias);
+                        }
+                        aux = normalize3(d);
+                        alive = true;
+                    }
+                } else {
+                    diffuse = true;
+                }
+            }
+            next += static_cast<uint32_t>(__popcll(mNew));
+            // 4. the next light of every diffuse entry that is not waiting for a shadow ray
+            if ((cur == kDone) & have & diffuse & !tracing) {
+                while (li < p.n_lights) {
+                    const LightRec Lt = lights[li];
+                    const F3 Lv = sub3(f3(Lt.x, Lt.y, Lt.z), Po);
+                    const float r2 = dot3(Lv, Lv);
+                    const float d1 = sqrtf(r2);
+                    const float invr = 1.0f / d1;
+                    const F3 Ldir = f3(Lv.x * invr, Lv.y * invr, Lv.z * invr);
+                    const float cosv = fmaxf(0.0f, dot3(N, Ldir));
+                    if (cosv > 0.0f) {
+                        sr = makeRay(Po, Ldir);
+                        dist = d1;
+                        tcull = d1 * kCullPad;
+                        kcur = (Lt.intensity / (kFourPi * r2)) * cosv;
+                        occluded = false;
+                        tracing = true;
+                        stack.sp = 0;
+                        cur = p.n_nodes ? 0 : kDone;
+                        if (COUNT) cntShadow++;
+                        break;
+                    }
+                    li++;
+                }
+            }
+            if (__ballot(have) == 0ull) break;
+        }
+        anyIteration<COUNT, BLOCK, 8>(nodes, tris, sr, 0.0f, dist, tcull, stack, innerMin, occluded, cur, iters, cntNodes, cntTris);
+    }
+}
+
+#ifndef CRT_PATH_WAVES_PER_EU
+#define CRT_PATH_WAVES_PER_EU 5
+#endif
+template <bool COUNT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAVES_PER_EU, 8))) void pathKernel(const RenderParams p)
+{
+    extern __shared__ int s_stack[];
+    const uint32_t frame = p.n_batch > 1u ? blockIdx.x % p.n_batch : 0u;
+    const uint32_t wg = p.n_batch > 1u ? blockIdx.x / p.n_batch : blockIdx.x;
+    const bool big = p.path_tile == 16u;                  // workgroup = whole macro tile (four 8x8 packets per sample) or one 8x8 packet
+    const uint32_t j = big ? wg : wg >> 2;                // position of the macro tile in this rank's list
+    const uint32_t subFirst = big ? 0u : (wg & 3u), subCount = big ? 4u : 1u;
+    const uint32_t tilePixels = subCount * 64u;
+    const float* camPos = frame ? p.batch_pos[frame - 1u] : p.pos;
+    const float* camRot = frame ? p.batch_rot[frame - 1u] : p.rot;
+    uint32_t* outRgba8 = frame ? p.batch_rgba8[frame - 1u] : p.rgba8;
+    uint32_t tile_x, tile_y;
+    bool valid;
+    if (p.n_ranks == 1) {
+        const uint32_t blocks_x = (p.tiles_x + 3u) >> 2;
+        const uint32_t blk = j >> 4, within = j & 15u;
+        tile_x = (blk % blocks_x) * 4u + (within & 3u);
+        tile_y = (blk / blocks_x) * 4u + (within >> 2);
+        valid = (tile_x < p.tiles_x) & (tile_y < p.tiles_y);
+    } else {
+        const uint32_t k = j * p.n_ranks + p.rank;
+        valid = k < p.tiles_x * p.tiles_y;
+        tile_x = k % p.tiles_x;
+        tile_y = k / p.tiles_x;
+    }
+    if (!valid) return;
+
+    const uint32_t lane = threadIdx.x & 63u;
+    const float4* nodes = reinterpret_cast<const float4*>(p.nodes);
+    const float4* tris = reinterpret_cast<const float4*>(p.tris);
+    Stack stack;
+    stack.lds = s_stack + lane;
+    stack.spill = p.spill + (static_cast<size_t>(blockIdx.x) * 64u + lane) * p.spill_stride;
+    stack.cap = static_cast<int>(p.stack_entries);
+    stack.sp = 0;
+    constexpr int BLOCK = 64;
+    const int innerMin = static_cast<int>(p.tune_inner_min);
+
+    PathScratch q;
+    q.B = tilePixels * p.path_samples;
+    {
+        float4* base = reinterpret_cast<float4*>(p.path_scratch + static_cast<size_t>(blockIdx.x) * p.path_region_bytes);
+        q.shade = base;
+        q.trace = q.shade + static_cast<size_t>(kShadePlanes) * q.B;
+        q.done = q.trace + static_cast<size_t>(kTracePlanes) * q.B;
+        q.thr = q.done + q.B;
+        q.accum = q.thr + q.B;
+    }
+    const F3 miss = f3(p.miss[0], p.miss[1], p.miss[2]);
+    uint32_t cntNodes = 0, cntTris = 0, cntShadow = 0, cntClosest = 0, iters = 0;
+
+    for (uint32_t s0 = 0; s0 < p.spp; s0 += p.path_samples) {
+        const uint32_t nS = min(p.path_samples, p.spp - s0);
+        uint32_t nShade = 0; // wave-uniform queue lengths
+        // ---- stage A: the tile's camera rays, one 8x8 packet of one sample at a time
+        for (uint32_t sl = 0; sl < nS; sl++) {
+            for (uint32_t sb = 0; sb < subCount; sb++) {
+                const uint32_t sub = subFirst + sb;
+                const uint32_t lx = (sub & 1u) * 8u + (lane & 7u), ly = (sub >> 1) * 8u + (lane >> 3);
+                const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
+                const bool active = (px < p.width) & (py < p.height);
+                const uint32_t id = sl * tilePixels + sb * 64u + lane; // path id inside the workgroup
+                bool isHit = false;
+                Ray r;
+                Hit h;
+                uint32_t rng = 0;
+                if (active) {
+                    const uint32_t pixId = py * p.width + px;
+                    rng = pcgHash(pixId ^ pcgHash((s0 + sl) + pcgHash(p.seed)));
+                    const float jx = rngNext(rng), jy = rngNext(rng);
+                    r = makeRay(f3(camPos[0], camPos[1], camPos[2]), rayDirJ(camRot, px, py, jx, jy, static_cast<float>(p.width), static_cast<float>(p.height)));
+                    if (COUNT) cntClosest++;
+                    traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, innerMin, h, iters, cntNodes, cntTris);
+                    isHit = h.t < kTMax;
+                    // radiance so far: a miss ends the path with throughput (1) x miss colour; a hit starts from nothing, throughput 1
+                    q.done[id] = isHit ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(fmaf(1.0f, miss.x, 0.0f), fmaf(1.0f, miss.y, 0.0f), fmaf(1.0f, miss.z, 0.0f), 0.0f);
+                    if (isHit) q.thr[id] = make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+                    if (s0 + sl == 0u && frame == 0u) { // the hit outputs report sample 0's camera ray
+                        const size_t pix = static_cast<size_t>(py) * p.width + px;
+                        uint32_t inst = 0xFFFFFFFFu, prim = 0xFFFFFFFFu;
+                        if (isHit) {
+                            const float4* T = tris + 3 * static_cast<size_t>(h.tri);
+                            inst = __float_as_uint(T[0].w);
+                            prim = __float_as_uint(T[1].w);
+                        }
+                        if (p.hit_inst) p.hit_inst[pix] = inst;
+                        if (p.hit_prim) p.hit_prim[pix] = prim;
+                        if (p.hit_t) p.hit_t[pix] = isHit ? h.t : kTMax;
+                    }
+                }
+                const unsigned long long m = __ballot(isHit);
+                if (isHit) {
+                    const uint32_t i = nShade + lanePrefix(m);
+                    q.shade[i] = make_float4(r.o.x, r.o.y, r.o.z, __uint_as_float(rng));
+                    q.shade[q.B + i] = make_float4(r.d.x, r.d.y, r.d.z, __uint_as_float(id)); // bounce 0 in the upper half
+                    q.shade[2u * q.B + i] = make_float4(h.t, h.u, h.v, __uint_as_float(h.tri));
+                }
+                nShade += static_cast<uint32_t>(__popcll(m));
+            }
+        }
+        // ---- stages B / C until no path is left
+        while (nShade != 0u) {
+            uint32_t nTrace = 0;
+            streamShade<COUNT>(p, nodes, tris, q, nShade, nTrace, stack, innerMin, iters, cntNodes, cntTris, cntShadow); // stage B
+            nShade = 0;
+            streamClosest<COUNT>(nodes, tris, p.n_nodes, q, nTrace, nShade, miss, stack, innerMin, iters, cntNodes, cntTris, cntClosest); // stage C
+        }
+        // ---- this pass's samples join the running sums in sample order; after the last pass: average, quantise, store
+        const bool last = s0 + nS >= p.spp;
+        for (uint32_t sb = 0; sb < subCount; sb++) {
+            const uint32_t sub = subFirst + sb;
+            const uint32_t lx = (sub & 1u) * 8u + (lane & 7u), ly = (sub >> 1) * 8u + (lane >> 3);
+            const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
+            if ((px < p.width) & (py < p.height)) {
+                const uint32_t pl = sb * 64u + lane;
+                F3 acc = f3(0.0f, 0.0f, 0.0f);
+                if (s0 != 0u) {
+                    const float4 a = q.accum[pl];
+                    acc = f3(a.x, a.y, a.z);
+                }
+                for (uint32_t sl = 0; sl < nS; sl++) {
+                    const float4 Ls = q.done[sl * tilePixels + pl];
+                    acc = f3(acc.x + Ls.x, acc.y + Ls.y, acc.z + Ls.z);
+                }
+                if (!last) {
+                    q.accum[pl] = make_float4(acc.x, acc.y, acc.z, 0.0f);
+                } else {
+                    const float inv = 1.0f / static_cast<float>(p.spp);
+                    const F3 col = f3(acc.x * inv, acc.y * inv, acc.z * inv);
+                    const uint32_t packed = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
+                    const size_t pix = static_cast<size_t>(py) * p.width + px;
+                    if (p.staging) outRgba8[static_cast<size_t>((tile_y * p.tiles_x + tile_x) / p.n_ranks) * (kTile * kTile) + ly * kTile + lx] = packed;
+                    else outRgba8[pix] = packed;
+                    if (p.rgb_f32 && frame == 0u) {
+                        p.rgb_f32[3 * pix + 0] = col.x;
+                        p.rgb_f32[3 * pix + 1] = col.y;
+                        p.rgb_f32[3 * pix + 2] = col.z;
+                    }
+                }
+            }
+        }
+    }
+    if (COUNT) {
+        const uint32_t a = waveSum(cntNodes), c = waveSum(cntTris), sh = waveSum(cntShadow), cl = waveSum(cntClosest);
+        if (lane == 0) {
+            atomicAdd(&p.counters[0], static_cast<unsigned long long>(a));
+            atomicAdd(&p.counters[1], static_cast<unsigned long long>(c));
+            atomicAdd(&p.counters[2], static_cast<unsigned long long>(sh));
+            atomicAdd(&p.counters[3], static_cast<unsigned long long>(cl));
+        }
+    }
+}
+
+} // namespace
+
+// scratch the path-tracing pipeline needs per workgroup (one macro tile): the two queues, the finished-path radiances and
+// the cross-pass sums; and how many workgroups launchRender starts for p in mode 200
+size_t pathRegionBytes(uint32_t tile, uint32_t samples_per_pass)
+{
+    const size_t pixels = static_cast<size_t>(tile) * tile, B = pixels * samples_per_pass;
+    return (kShadePlanes + kTracePlanes + 2u) * B * sizeof(float4) + pixels * sizeof(float4); // queues + radiance + throughput, + cross-pass sums
+}
+uint32_t pathWorkgroupCount(const RenderParams& p) { return renderUnitCount(p) / (p.path_tile == 16u ? 4u : 1u) * (p.n_batch ? p.n_batch : 1u); }
+
+int launchPath(const RenderParams& p, bool counting, ihipStream_t* stream)
+{
+    // one wavefront per pixel tile carries all its paths through the pipeline
+    const dim3 grid(pathWorkgroupCount(p)), block(64);
+    const size_t lds = static_cast<size_t>(p.stack_entries) * 64u * sizeof(int);
+    if (counting) hipLaunchKernelGGL((pathKernel<true>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((pathKernel<false>), grid, block, lds, stream, p);
+    return static_cast<int>(hipGetLastError());
+}
+
+} // namespace crt

@@ -1,4 +1,4 @@
-// Launch interface between the C-ABI layer (crt_api.cpp, host C++) and the HIP kernels (render_kernels.hip).
+// Launch interface between the C-ABI layer (crt_api.cpp, host C++) and the HIP kernels (render_kernels.hip, path_kernels.hip; device code shared through traversal.hip.h / shading.hip.h).
 #pragma once
 
 #include <cstdint>
@@ -19,7 +19,7 @@ struct RenderParams {
     const void* lights;  // crt_light[n_lights]
     const void* mats;    // crt_material[n_mats] (28 B)
     const void* uvs;     // crt_bvh_uv[n_tris] (24 B, leaf order) or null
-    const void* textures; // TextureRec[n_textures] (render_kernels.hip), bitmaps' texels in `texels`
+    const void* textures; // TextureRec[n_textures] (below), bitmaps' texels in `texels`
     const unsigned char* texels;
     uint32_t n_textures;
     uint32_t n_nodes, n_tris, n_lights, n_mats;
@@ -62,7 +62,7 @@ struct RenderParams {
     float batch_pos[3][3];
     float batch_rot[3][9];
     uint32_t* batch_rgba8[3];
-    // mode 200: per-workgroup scratch of the wavefront-private path pipeline (render_kernels.hip pathKernel)
+    // mode 200: per-workgroup scratch of the wavefront-private path pipeline (path_kernels.hip pathKernel)
     unsigned char* path_scratch;  // pathWorkgroupCount() regions of path_region_bytes
     size_t path_region_bytes;     // pathRegionBytes(path_samples)
     uint32_t path_tile;           // 16: one workgroup per 16x16 macro tile; 8: one per 8x8 packet
@@ -74,6 +74,8 @@ struct RenderParams {
 int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream);
 // number of work units (= workgroups) launchRender uses for p: size of unit_order / unit_cost
 uint32_t renderUnitCount(const RenderParams& p);
+// mode 200 (path_kernels.hip): the wavefront-private path pipeline; launchRender forwards to launchPath
+int launchPath(const RenderParams& p, bool counting, ihipStream_t* stream);
 // mode 200 scratch sizing
 size_t pathRegionBytes(uint32_t tile, uint32_t samples_per_pass);
 uint32_t pathWorkgroupCount(const RenderParams& p);

@@ -1,0 +1,631 @@
+// Device-side traversal shared by the render kernel (render_kernels.hip) and the path-tracing pipeline (path_kernels.hip):
+// vector helpers, the ray, Moeller-Trumbore, the per-lane LDS stack, the quantised wide-node step and the wave-scheduled
+// closest-hit / any-hit traversals.  Everything is internal to the including translation unit (anonymous namespace).
+//
+// Arithmetic contract: identical, operation for operation, to oracle/crt_oracle.c (compiled with
+// -ffp-contract=off; fused multiply-adds only where fmaf()/fma() is written; correctly rounded / and sqrt).
+#pragma once
+
+#include "render_kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <climits>
+
+namespace crt {
+namespace {
+
+
+constexpr float kTMin = 0.001f;   // hlsl:51
+constexpr float kTMax = 10000.0f; // hlsl:52
+constexpr float kDirEps = 1e-20f;
+constexpr float kCullPad = 1.00000381469726562f; // 1 + 2^-18, see oracle trace_closest
+constexpr float kShadowBias = 1e-3f;
+constexpr float kFourPi = 12.566370614359172f;
+constexpr int kDone = INT_MIN;    // traversal finished (not a valid leaf reference)
+constexpr int kBlock = 256;
+constexpr uint32_t kBoostAfter = 300;
+#ifndef NODE_STEPS
+#define NODE_STEPS 2
+#endif
+#ifndef CRT_PROF
+#define CRT_PROF 0
+#endif
+// diagnostics that change what a frame does or costs (per-workgroup timeline stamps, dropping the most expensive
+// packets): only in the diagnostic builds of tools/diag_build.sh / tools/prof_build.sh, never in the product
+#ifndef CRT_DIAG
+#define CRT_DIAG CRT_PROF
+#endif
+// Register budget: the primary/shadow-ray variant is asked for 7 wavefronts per SIMD (<= 72 VGPRs; one register spilled
+// outside the loops).  With the 64-byte quantised nodes a node in flight is 16 registers instead of 28, and with the LDS
+// stack at 16 entries (4 KB per wavefront) the CU holds those 28 wavefronts: 0.295 ms against 0.306 at 6 per SIMD;
+// 8 per SIMD (64 VGPRs) spills inside the loops (0.37).  The path-tracing variant keeps the compiler's choice.
+#ifndef CRT_WAVES_PER_EU
+#define CRT_WAVES_PER_EU 7
+#endif
+#define CRT_OCCUPANCY_ATTR __attribute__((amdgpu_waves_per_eu(CRT_WAVES_PER_EU, 8)))
+// scalar-cache fetches of records a whole wavefront shares (see loadNodeUniform): in the descent from the root, in any
+// node step whose lanes agree, and in leaves
+#ifndef UNIFORM_DESCENT
+#define UNIFORM_DESCENT 1
+#endif
+#ifndef UNIFORM_STEP
+#define UNIFORM_STEP 1
+#endif
+#ifndef UNIFORM_LEAF
+#define UNIFORM_LEAF 1
+#endif
+#ifndef LEAF_PAIRS
+#define LEAF_PAIRS 1
+#endif
+#ifndef OCTANT_SPECIALISE
+#define OCTANT_SPECIALISE 1
+#endif // traversal-loop iterations after which a wavefront raises its issue priority
+constexpr uint32_t kGroupMax = 16; // grid padding unit: tiles per XCD group never exceed this
+
+struct F3 { float x, y, z; };
+
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{ x, y, z }; }
+__device__ __forceinline__ F3 sub3(F3 a, F3 b) { return f3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return fmaf(a.z, b.z, fmaf(a.y, b.y, a.x * b.x)); }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b)
+{
+    return f3(fmaf(a.y, b.z, -(a.z * b.y)), fmaf(a.z, b.x, -(a.x * b.z)), fmaf(a.x, b.y, -(a.y * b.x)));
+}
+__device__ __forceinline__ F3 normalize3(F3 a)
+{
+    const float inv = 1.0f / sqrtf(dot3(a, a));
+    return f3(a.x * inv, a.y * inv, a.z * inv);
+}
+__device__ __forceinline__ float frac1(float x) { return x - floorf(x); }
+__device__ __forceinline__ float saturate1(float x) { return fminf(fmaxf(x, 0.0f), 1.0f); }
+__device__ __forceinline__ float lerp1(float a, float b, float t) { return a + t * (b - a); }
+
+// sin() with the operation sequence of oracle_sinf: Cody-Waite reduction by 2*pi in double, odd Taylor
+// polynomial to r^23 (Horner, fma), one rounding to float.  fp64 runs at full rate on CDNA4.
+__device__ __forceinline__ float sinContract(float x)
+{
+    const double xd = static_cast<double>(x);
+    const double k = rint(xd * 0x1.45f306dc9c883p-3);
+    double r = fma(-k, 0x1.921fb54442d18p+2, xd);
+    r = fma(-k, 0x1.1a62633145c07p-52, r);
+    const double r2 = r * r;
+    double p = -0x1.761b41316381ap-75;
+    p = fma(p, r2, 0x1.71b8ef6dcf572p-66);
+    p = fma(p, r2, -0x1.2f49b46814157p-57);
+    p = fma(p, r2, 0x1.952c77030ad4ap-49);
+    p = fma(p, r2, -0x1.ae7f3e733b81fp-41);
+    p = fma(p, r2, 0x1.6124613a86d09p-33);
+    p = fma(p, r2, -0x1.ae64567f544e4p-26);
+    p = fma(p, r2, 0x1.71de3a556c734p-19);
+    p = fma(p, r2, -0x1.a01a01a01a01ap-13);
+    p = fma(p, r2, 0x1.1111111111111p-7);
+    p = fma(p, r2, -0x1.5555555555555p-3);
+    p = p * r2;
+    return static_cast<float>(fma(p, r, r));
+}
+__device__ __forceinline__ float hashSin(float x, float k) { return frac1(sinContract(x) * k); }
+
+__device__ __forceinline__ uint32_t unorm8(float c) { return static_cast<uint32_t>(saturate1(c) * 255.0f + 0.5f); }
+
+struct Ray {
+    F3 o, d;
+    F3 idir, noid;
+};
+
+__device__ __forceinline__ float safeRcp(float d)
+{
+    const float ds = (fabsf(d) < kDirEps) ? copysignf(kDirEps, d) : d;
+    return 1.0f / ds;
+}
+
+__device__ __forceinline__ Ray makeRay(F3 o, F3 d)
+{
+    Ray r;
+    r.o = o;
+    r.d = d;
+    r.idir = f3(safeRcp(d.x), safeRcp(d.y), safeRcp(d.z));
+    r.noid = f3(-(o.x * r.idir.x), -(o.y * r.idir.y), -(o.z * r.idir.z));
+    return r;
+}
+
+// Moeller-Trumbore, two sided; u = weight of v1, v = weight of v2.  NaN/inf from det == 0 fail the compares.
+__device__ __forceinline__ bool triTest(const Ray& r, const float4 a, const float4 b, const float4 c, float tmin,
+                                        float& t, float& u, float& v)
+{
+    const F3 e1 = f3(b.x, b.y, b.z), e2 = f3(c.x, c.y, c.z);
+    const F3 p = cross3(r.d, e2);
+    const float det = dot3(e1, p);
+    const float inv = 1.0f / det;
+    const F3 s = sub3(r.o, f3(a.x, a.y, a.z));
+    u = dot3(s, p) * inv;
+    const F3 q = cross3(s, e1);
+    v = dot3(r.d, q) * inv;
+    t = dot3(e2, q) * inv;
+    return (u >= 0.0f) & (v >= 0.0f) & (u + v <= 1.0f) & (t > tmin);
+}
+
+// Per-lane traversal stack.  The first `cap` entries live in LDS (entry e of lane l at dword e*64+l: conflict free); cap
+// is chosen so that 26 wavefronts per CU fit its 160 KB (24 entries = 6 KB per wavefront).  No ray of the test scenes ever holds more than 15
+// entries while the trees are 24..26 deep, but the builder allows depth 32, so deeper entries spill to a per-lane slice
+// of a global arena that is never touched otherwise: any tree stays correct with the small LDS footprint.
+struct Stack {
+    int* lds;    // s_stack + lane
+    int* spill;  // arena slice of this lane: kStackEntries - cap entries are ever needed, kStackEntries reserved
+    int cap;     // wave-uniform
+    int sp;
+#if CRT_PROF // diagnostic build (tools/prof_build.sh): where a wavefront's cycles go, never compiled into the product
+    unsigned long long tNode = 0, tLeaf = 0;
+    uint32_t itNode = 0, itLeaf = 0, lanesNode = 0, lanesLeaf = 0;
+    // divergent (per-lane fetched) steps: how many, lanes in them, runs of consecutive lanes on the same record, distinct records
+    uint32_t dvN = 0, dvNLanes = 0, dvNRuns = 0, dvNDistinct = 0, dvL = 0, dvLLanes = 0, dvLRuns = 0, dvLDistinct = 0, unN = 0, unL = 0;
+    __device__ __forceinline__ void divStats(int cur, uint32_t& steps, uint32_t& lanes, uint32_t& runs, uint32_t& distinct)
+    {
+        const unsigned long long act = __ballot(true);
+        const int prev = __shfl_up(cur, 1, 64);
+        const uint32_t lane = threadIdx.x & 63u;
+        const bool prevActive = lane > 0 && ((act >> (lane - 1)) & 1ull);
+        runs += __popcll(__ballot(!prevActive || prev != cur));
+        steps++;
+        lanes += __popcll(act);
+        unsigned long long rest = act;
+        while (rest) {
+            const int first = __ffsll(static_cast<long long>(rest)) - 1;
+            const int v = __shfl(cur, first, 64);
+            rest &= ~__ballot(cur == v);
+            distinct++;
+        }
+    }
+#endif
+    __device__ __forceinline__ void push(int v)
+    {
+        if (sp < cap) lds[sp * 64] = v;
+        else spill[sp - cap] = v;
+        sp++;
+    }
+    __device__ __forceinline__ int pop()
+    {
+        sp--;
+        return sp < cap ? lds[sp * 64] : spill[sp - cap];
+    }
+};
+
+struct Hit {
+    float t, u, v;
+    uint32_t tri; // leaf-order triangle index
+    uint32_t gid;
+};
+
+// ---- wide (4-child) node step.  Node = crt_bvh_node4q, 64 bytes = four dwordx4 loads:
+//   {lo.x lo.y lo.z s.x} {s.y s.z qlo_x qhi_x} {qlo_y qhi_y qlo_z qhi_z} {ref[4]}
+// The child planes are 8-bit offsets from the node's own minimum corner (byte k of a q word = child k): plane =
+// fma(q, s, lo).  The vector memory pipe -- per-lane fetch requests -- is what bounds this kernel, not vector arithmetic
+// (30 extra dependent VALU per step measured +0.5 %, one extra 4-byte touch per pushed child +29 %), so the record is
+// kept to four requests per lane instead of the seven of a full-precision node and decoded in registers.  The decode is
+// folded into the slab test: t(q) = fma(q, s * idir, fma(lo, idir, -o * idir)), monotonic in q with the sign of idir, so
+// for a known direction octant (OCT < 8) the near plane of each axis is a fixed member of the (qlo, qhi) pair and the
+// min/max pairs of the generic form (OCT = 8) disappear -- bit for bit the same values.
+// One memory round trip yields four slab tests (15.6 instead of 29.7 steps per ray on the 1M-triangle frame).
+// An unused child slot has ref CRT_BVH_EMPTY (tested explicitly).
+constexpr int kEmptyRef = INT_MIN;
+
+// one wide node in registers; fetched per lane (four dwordx4 vector loads) or, when the whole wavefront stands on the
+// same node, once through the scalar cache (constant address space + wave-uniform address = one s_load_dwordx16)
+struct NodeRegs {
+    float4 q0, q1, q2;
+    int4 refs;
+};
+constexpr size_t kNodeQuads = 4; // float4 per node record
+
+__device__ __forceinline__ float ubyteToFloat(uint32_t w, int k) { return static_cast<float>((w >> (8 * k)) & 0xFFu); } // v_cvt_f32_ubyteK
+
+template <int OCT>
+__device__ __forceinline__ void slab4(const NodeRegs& nd, const Ray& r, float tmin, float tcull, float tn[4], bool hit[4])
+{
+    const float ax = nd.q0.w * r.idir.x, ay = nd.q1.x * r.idir.y, az = nd.q1.y * r.idir.z;
+    const float bx = fmaf(nd.q0.x, r.idir.x, r.noid.x), by = fmaf(nd.q0.y, r.idir.y, r.noid.y), bz = fmaf(nd.q0.z, r.idir.z, r.noid.z);
+    const uint32_t lx = __float_as_uint(nd.q1.z), hx = __float_as_uint(nd.q1.w), ly = __float_as_uint(nd.q2.x), hy = __float_as_uint(nd.q2.y),
+                   lz = __float_as_uint(nd.q2.z), hz = __float_as_uint(nd.q2.w);
+    const int rf[4] = { nd.refs.x, nd.refs.y, nd.refs.z, nd.refs.w };
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        float t_n, t_f;
+        if (OCT < 8) {
+            const float nx = ubyteToFloat((OCT & 1) ? hx : lx, k), fx = ubyteToFloat((OCT & 1) ? lx : hx, k);
+            const float ny = ubyteToFloat((OCT & 2) ? hy : ly, k), fy = ubyteToFloat((OCT & 2) ? ly : hy, k);
+            const float nz = ubyteToFloat((OCT & 4) ? hz : lz, k), fz = ubyteToFloat((OCT & 4) ? lz : hz, k);
+            t_n = fmaxf(fmaxf(fmaf(nx, ax, bx), fmaf(ny, ay, by)), fmaxf(fmaf(nz, az, bz), tmin));
+            t_f = fminf(fminf(fmaf(fx, ax, bx), fmaf(fy, ay, by)), fminf(fmaf(fz, az, bz), tcull));
+        } else {
+            const float x0 = fmaf(ubyteToFloat(lx, k), ax, bx), x1 = fmaf(ubyteToFloat(hx, k), ax, bx);
+            const float y0 = fmaf(ubyteToFloat(ly, k), ay, by), y1 = fmaf(ubyteToFloat(hy, k), ay, by);
+            const float z0 = fmaf(ubyteToFloat(lz, k), az, bz), z1 = fmaf(ubyteToFloat(hz, k), az, bz);
+            t_n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
+            t_f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tcull));
+        }
+        tn[k] = t_n;
+        hit[k] = (t_n <= t_f) & (rf[k] != kEmptyRef);
+    }
+}
+
+__device__ __forceinline__ NodeRegs loadNode(const float4* __restrict__ N)
+{
+    NodeRegs nd;
+    nd.q0 = N[0]; nd.q1 = N[1]; nd.q2 = N[2];
+    nd.refs = *reinterpret_cast<const int4*>(N + 3);
+    return nd;
+}
+__device__ __forceinline__ __attribute__((unused)) NodeRegs loadNodeUniform(const float4* N)
+{
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) f4v* ConstPtr;
+    ConstPtr C = (ConstPtr)(reinterpret_cast<uintptr_t>(N));
+    const f4v a = C[0], b = C[1], c = C[2], g = C[3];
+    NodeRegs nd;
+    nd.q0 = make_float4(a.x, a.y, a.z, a.w); nd.q1 = make_float4(b.x, b.y, b.z, b.w); nd.q2 = make_float4(c.x, c.y, c.z, c.w);
+    nd.refs = make_int4(__float_as_int(g.x), __float_as_int(g.y), __float_as_int(g.z), __float_as_int(g.w));
+    return nd;
+}
+
+__device__ __forceinline__ __attribute__((unused)) void loadTriUniform(const float4* T, float4& a, float4& b, float4& c)
+{
+    typedef float f4v __attribute__((ext_vector_type(4)));
+    typedef const __attribute__((address_space(4))) f4v* ConstPtr;
+    ConstPtr C = (ConstPtr)(reinterpret_cast<uintptr_t>(T));
+    const f4v x = C[0], y = C[1], z = C[2];
+    a = make_float4(x.x, x.y, x.z, x.w); b = make_float4(y.x, y.y, y.z, y.w); c = make_float4(z.x, z.y, z.z, z.w);
+}
+
+__device__ __forceinline__ int pick4(const int4& v, uint32_t i) // v[i], i in 0..3, without dynamic register indexing
+{
+    const int lo = (i & 1u) ? v.y : v.x, hi = (i & 1u) ? v.w : v.z;
+    return (i & 2u) ? hi : lo;
+}
+
+// closest hit: visit the hit children nearest first.  Order key = (bits(t_near) & 0x7FFFFFFC) | slot: t_near >= 0 so its
+// bit pattern orders like the float, the two low bits hold the slot (keys are unique, order is total and identical in
+// the oracle); misses get 0xFFFFFFFF.  Five min/max pairs sort the four keys.
+template <bool COUNT, int BLOCK, int OCT>
+__device__ __forceinline__ void nodeStepClosestAt(const NodeRegs& nd, const Ray& r, float tmin, float tcull, Stack& stack,
+                                                  int& cur, uint32_t& cntNodes)
+{
+    const int4 refs = nd.refs;
+    if (COUNT) cntNodes++;
+    float tn[4];
+    bool hit[4];
+    slab4<OCT>(nd, r, tmin, tcull, tn, hit);
+    uint32_t key[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        key[k] = hit[k] ? ((__float_as_uint(tn[k]) & 0x7FFFFFFCu) | static_cast<uint32_t>(k)) : 0xFFFFFFFFu;
+#define CRT_CSWAP(a, b) { const uint32_t lo = min(key[a], key[b]), hi = max(key[a], key[b]); key[a] = lo; key[b] = hi; }
+    CRT_CSWAP(0, 1) CRT_CSWAP(2, 3) CRT_CSWAP(0, 2) CRT_CSWAP(1, 3) CRT_CSWAP(1, 2)
+#undef CRT_CSWAP
+    if (key[0] == 0xFFFFFFFFu) {
+        cur = stack.sp == 0 ? kDone : stack.pop();
+    } else {
+        if (key[3] != 0xFFFFFFFFu) stack.push(pick4(refs, key[3] & 3u)); // farthest first: the nearest pending child pops first
+        if (key[2] != 0xFFFFFFFFu) stack.push(pick4(refs, key[2] & 3u));
+        if (key[1] != 0xFFFFFFFFu) stack.push(pick4(refs, key[1] & 3u));
+        cur = pick4(refs, key[0] & 3u);
+    }
+}
+
+// any hit: order independent, children taken in slot order
+template <bool COUNT, int BLOCK, int OCT>
+__device__ __forceinline__ void nodeStepAnyAt(const NodeRegs& nd, const Ray& r, float tmin, float tcull, Stack& stack,
+                                              int& cur, uint32_t& cntNodes)
+{
+    const int4 refs = nd.refs;
+    if (COUNT) cntNodes++;
+    float tn[4];
+    bool hit[4];
+    slab4<OCT>(nd, r, tmin, tcull, tn, hit);
+    const bool h0 = hit[0], h1 = hit[1], h2 = hit[2], h3 = hit[3];
+    if (!(h0 | h1 | h2 | h3)) {
+        cur = stack.sp == 0 ? kDone : stack.pop();
+    } else {
+        // first hit slot becomes current; later hit slots are pushed, last slot first
+        if (h3 & (h0 | h1 | h2)) stack.push(refs.w);
+        if (h2 & (h0 | h1)) stack.push(refs.z);
+        if (h1 & h0) stack.push(refs.y);
+        cur = h0 ? refs.x : (h1 ? refs.y : (h2 ? refs.z : refs.w));
+    }
+}
+
+// Uniform descent: the rays of an 8x8 packet start at the root and usually agree on the first few nodes.  While every
+// active lane stands on the SAME inner node its record is fetched once through the scalar cache (the node address is
+// wave-uniform, so the loads become s_load) instead of 64 identical per-lane vector fetches; each lane still runs its own
+// slab tests, ordering and pushes, so results and counters are exactly those of the per-lane loop that follows.
+#if UNIFORM_DESCENT
+#define CRT_UNIFORM_DESCENT(STEP)                                                                                              \
+    for (;;) {                                                                                                                 \
+        const int c0 = __builtin_amdgcn_readfirstlane(cur);                                                                    \
+        if (c0 < 0 || __ballot(cur != c0) != 0ull) break;                                                                      \
+        STEP<COUNT, BLOCK, OCT>(loadNodeUniform(nodes + kNodeQuads * static_cast<size_t>(c0)), r, tmin, tcull, stack, cur, cntNodes);   \
+    }
+#else
+#define CRT_UNIFORM_DESCENT(STEP)
+#endif
+// One node step of the lanes standing on inner nodes (called with exactly those lanes active): through the scalar cache
+// when they all stand on the same node, per lane otherwise.
+#if CRT_PROF
+#define CRT_DIV_STATS_NODE stack.divStats(cur, stack.dvN, stack.dvNLanes, stack.dvNRuns, stack.dvNDistinct);
+#define CRT_DIV_STATS_LEAF stack.divStats(cur, stack.dvL, stack.dvLLanes, stack.dvLRuns, stack.dvLDistinct);
+#else
+#define CRT_DIV_STATS_NODE
+#define CRT_DIV_STATS_LEAF
+#endif
+// One node step of the lanes standing on inner nodes (called with exactly those lanes active): through the scalar cache
+// when they all stand on the same node, per lane otherwise.
+// (Measured and rejected: fetching the DISTINCT nodes of a divergent step once each -- 6.6 distinct nodes among 50 wanting
+// lanes on the 1M-triangle frame -- by the first lanes of the wavefront and handing them out through LDS: a scalar loop
+// peels the distinct values, fetchers load and ds_write, every lane ds_reads its slot.  Bit-exact, a seventh of the
+// per-lane requests, and 0.49 ms instead of 0.31: the peeling loop and two LDS round trips per step cost far more than
+// the requests they save.)
+#if UNIFORM_STEP
+#define CRT_NODE_STEP(STEP)                                                                                                    \
+    {                                                                                                                          \
+        const int c0 = __builtin_amdgcn_readfirstlane(cur);                                                                    \
+        if (__ballot(cur != c0) == 0ull) {                                                                                     \
+            STEP<COUNT, BLOCK, OCT>(loadNodeUniform(nodes + kNodeQuads * static_cast<size_t>(c0)), r, tmin, tcull, stack, cur, cntNodes); \
+        } else {                                                                                                               \
+            CRT_DIV_STATS_NODE                                                                                                 \
+            STEP<COUNT, BLOCK, OCT>(loadNode(nodes + kNodeQuads * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);     \
+        }                                                                                                                      \
+    }
+#else
+#define CRT_NODE_STEP(STEP) STEP<COUNT, BLOCK, OCT>(loadNode(nodes + kNodeQuads * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);
+#endif
+
+// Wave-level scheduling shared by both traversals.  Every lane walks its own ray in its own fixed order (so results
+// and counters do not depend on what the other lanes do), but WHEN a lane's next step runs is decided per wavefront:
+// node steps are issued while at least `innerMin` lanes still stand on inner nodes (or nobody waits at a leaf); then the
+// lanes waiting at leaves intersect their triangles.  innerMin = 1 is the classic while-while loop (leaves wait until
+// every lane has one: 47 % of the lanes active on the 1M-triangle frame); 32 measured best (first measurement: 0.67 vs 1.10 ms; re-swept after every structural change).
+// One scheduling decision of the closest-hit traversal for the whole wavefront: NODE_STEPS node steps of the lanes standing
+// on inner nodes, or the leaf step of the lanes waiting at leaves.  Per-lane state (cur, stack, h, tcull) lives in the
+// caller, so a caller may retire finished rays and start new ones between two calls (streamClosest).  Returns false when
+// no lane has anything left to do.
+template <bool COUNT, int BLOCK, int OCT>
+__device__ __forceinline__ bool closestIteration(const float4* __restrict__ nodes, const float4* __restrict__ tris, const Ray& r, float tmin,
+                                                 float& tcull, Stack& stack, int innerMin, Hit& h, int& cur, uint32_t& iters,
+                                                 uint32_t& cntNodes, uint32_t& cntTris)
+{
+    const unsigned long long innerMask = __ballot(cur >= 0);
+    const unsigned long long leafMask = __ballot((cur < 0) & (cur != kDone));
+    if ((innerMask | leafMask) == 0ull) return false;
+    if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3); // a wavefront on a long critical path stops queueing behind the others
+    if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
+#if CRT_PROF
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+        for (int rep = 0; rep < NODE_STEPS; rep++) { // several node steps per scheduling decision: fewer ballots/branches
+            if (cur >= 0) CRT_NODE_STEP(nodeStepClosestAt)
+        }
+#if CRT_PROF
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stack.tNode += __builtin_amdgcn_s_memtime() - ts0; stack.itNode++; stack.lanesNode += __popcll(innerMask);
+#endif
+        return true;
+    }
+#if CRT_PROF
+    const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+    stack.itLeaf++; stack.lanesLeaf += __popcll(leafMask);
+#endif
+    if ((cur < 0) & (cur != kDone)) {
+        const uint32_t code = static_cast<uint32_t>(~cur);
+        const uint32_t first = code >> 3, cnt = code & 7u;
+#if UNIFORM_LEAF
+        const int lc0 = __builtin_amdgcn_readfirstlane(cur);
+        if (__ballot(cur != lc0) == 0ull) {
+            // every waiting lane stands on the same leaf: its triangles come through the scalar cache, once per wavefront
+            const uint32_t ucode = static_cast<uint32_t>(~lc0);
+            const uint32_t ufirst = ucode >> 3, ucnt = ucode & 7u;
+            for (uint32_t i = ufirst; i < ufirst + ucnt; i++) {
+                float4 a, b, c;
+                loadTriUniform(tris + 3 * static_cast<size_t>(i), a, b, c);
+                if (COUNT) cntTris++;
+                float t, u, v;
+                if (triTest(r, a, b, c, tmin, t, u, v)) {
+                    const uint32_t gid = __float_as_uint(c.w);
+                    if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
+                        h.t = t; h.u = u; h.v = v; h.tri = i; h.gid = gid;
+                        tcull = t * kCullPad;
+                    }
+                }
+            }
+        } else
+#endif
+#if LEAF_PAIRS
+        CRT_DIV_STATS_LEAF
+        // two triangles per memory round trip (same test order): the second record's loads overlap the first's
+        for (uint32_t i = first; i < first + cnt; i += 2) {
+            const bool two = i + 1 < first + cnt;
+            const float4* T = tris + 3 * static_cast<size_t>(i);
+            const float4* T1 = two ? T + 3 : T;
+            const float4 a = T[0], b = T[1], c = T[2];
+            const float4 a1 = T1[0], b1 = T1[1], c1 = T1[2];
+            if (COUNT) cntTris += two ? 2u : 1u;
+            float t, u, v;
+            if (triTest(r, a, b, c, tmin, t, u, v)) {
+                const uint32_t gid = __float_as_uint(c.w);
+                if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
+                    h.t = t; h.u = u; h.v = v; h.tri = i; h.gid = gid;
+                    tcull = t * kCullPad;
+                }
+            }
+            if (two & triTest(r, a1, b1, c1, tmin, t, u, v)) {
+                const uint32_t gid = __float_as_uint(c1.w);
+                if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
+                    h.t = t; h.u = u; h.v = v; h.tri = i + 1; h.gid = gid;
+                    tcull = t * kCullPad;
+                }
+            }
+        }
+#else
+        for (uint32_t i = first; i < first + cnt; i++) {
+            const float4* T = tris + 3 * static_cast<size_t>(i);
+            const float4 a = T[0], b = T[1], c = T[2];
+            if (COUNT) cntTris++;
+            float t, u, v;
+            if (triTest(r, a, b, c, tmin, t, u, v)) {
+                const uint32_t gid = __float_as_uint(c.w);
+                if ((t < h.t) | ((t == h.t) & (gid < h.gid))) {
+                    h.t = t; h.u = u; h.v = v; h.tri = i; h.gid = gid;
+                    tcull = t * kCullPad;
+                }
+            }
+        }
+#endif
+        cur = stack.sp == 0 ? kDone : stack.pop();
+    }
+#if CRT_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    stack.tLeaf += __builtin_amdgcn_s_memtime() - tl0;
+#endif
+    return true;
+}
+
+template <bool COUNT, int BLOCK, int OCT>
+__device__ __forceinline__ void traceClosestOct(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                             uint32_t n_nodes, const Ray& r, float tmin, float tmax, Stack& stack, int innerMin,
+                                             Hit& h, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris)
+{
+    h.t = tmax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
+    int cur = n_nodes ? 0 : kDone;
+    stack.sp = 0;
+    float tcull = tmax * kCullPad; // boxes are culled against best_t * pad; changes only when a hit is accepted
+    CRT_UNIFORM_DESCENT(nodeStepClosestAt)
+    while (closestIteration<COUNT, BLOCK, OCT>(nodes, tris, r, tmin, tcull, stack, innerMin, h, cur, iters, cntNodes, cntTris)) {}
+}
+
+// One scheduling decision of the any-hit traversal (see closestIteration); tmax / tcull / occluded are per-lane state of the caller
+template <bool COUNT, int BLOCK, int OCT>
+__device__ __forceinline__ bool anyIteration(const float4* __restrict__ nodes, const float4* __restrict__ tris, const Ray& r, float tmin, float tmax,
+                                             float tcull, Stack& stack, int innerMin, bool& occluded, int& cur, uint32_t& iters,
+                                             uint32_t& cntNodes, uint32_t& cntTris)
+{
+    const unsigned long long innerMask = __ballot(cur >= 0);
+    const unsigned long long leafMask = __ballot((cur < 0) & (cur != kDone));
+    if ((innerMask | leafMask) == 0ull) return false;
+    if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3);
+    if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
+#if CRT_PROF
+        const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+#endif
+#pragma unroll
+        for (int rep = 0; rep < NODE_STEPS; rep++) {
+            if (cur >= 0) CRT_NODE_STEP(nodeStepAnyAt)
+        }
+#if CRT_PROF
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        stack.tNode += __builtin_amdgcn_s_memtime() - ts0; stack.itNode++; stack.lanesNode += __popcll(innerMask);
+#endif
+        return true;
+    }
+#if CRT_PROF
+    const unsigned long long tl0 = __builtin_amdgcn_s_memtime();
+    stack.itLeaf++; stack.lanesLeaf += __popcll(leafMask);
+#endif
+    if ((cur < 0) & (cur != kDone)) {
+        const uint32_t code = static_cast<uint32_t>(~cur);
+        const uint32_t first = code >> 3, cnt = code & 7u;
+#if UNIFORM_LEAF
+        const int lc0 = __builtin_amdgcn_readfirstlane(cur);
+        if (__ballot(cur != lc0) == 0ull) {
+            const uint32_t ucode = static_cast<uint32_t>(~lc0);
+            const uint32_t ufirst = ucode >> 3, ucnt = ucode & 7u;
+            for (uint32_t i = ufirst; i < ufirst + ucnt; i++) {
+                float4 a, b, c;
+                loadTriUniform(tris + 3 * static_cast<size_t>(i), a, b, c);
+                if (COUNT) cntTris++;
+                float t, u, v;
+                if (triTest(r, a, b, c, tmin, t, u, v) & (t < tmax)) {
+                    occluded = true;
+                    break;
+                }
+            }
+        } else
+#endif
+        for (uint32_t i = first; i < first + cnt; i++) {
+            const float4* T = tris + 3 * static_cast<size_t>(i);
+            const float4 a = T[0], b = T[1], c = T[2];
+            if (COUNT) cntTris++;
+            float t, u, v;
+            if (triTest(r, a, b, c, tmin, t, u, v) & (t < tmax)) {
+                occluded = true;
+                break;
+            }
+        }
+        cur = (occluded | (stack.sp == 0)) ? kDone : stack.pop();
+    }
+#if CRT_PROF
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    stack.tLeaf += __builtin_amdgcn_s_memtime() - tl0;
+#endif
+    return true;
+}
+
+template <bool COUNT, int BLOCK, int OCT>
+__device__ __forceinline__ bool traceAnyOct(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                         uint32_t n_nodes, const Ray& r, float tmin, float tmax, Stack& stack, int innerMin,
+                                         uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris)
+{
+    bool occluded = false;
+    int cur = n_nodes ? 0 : kDone;
+    stack.sp = 0;
+    const float tcull = tmax * kCullPad;
+    CRT_UNIFORM_DESCENT(nodeStepAnyAt)
+    while (anyIteration<COUNT, BLOCK, OCT>(nodes, tris, r, tmin, tmax, tcull, stack, innerMin, occluded, cur, iters, cntNodes, cntTris)) {}
+    return occluded;
+}
+
+// Pick the traversal loop specialised for the wavefront's direction octant when all its active lanes share one (nearly
+// every 8x8 camera packet and every packet of shadow rays towards one light does); otherwise the generic loop.
+__device__ __forceinline__ uint32_t octantOf(const Ray& r)
+{
+    return (__float_as_uint(r.d.x) >> 31) | ((__float_as_uint(r.d.y) >> 31) << 1) | ((__float_as_uint(r.d.z) >> 31) << 2);
+}
+
+template <bool COUNT, int BLOCK>
+__device__ __forceinline__ void traceClosest(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                             uint32_t n_nodes, const Ray& r, float tmin, float tmax, Stack& stack, int innerMin,
+                                             Hit& h, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris)
+{
+#if OCTANT_SPECIALISE
+    const uint32_t oct = octantOf(r);
+    const uint32_t o0 = __builtin_amdgcn_readfirstlane(oct);
+    if (__ballot(oct != o0) == 0ull) {
+        switch (o0) {
+#define CRT_CASE(k) case k: traceClosestOct<COUNT, BLOCK, k>(nodes, tris, n_nodes, r, tmin, tmax, stack, innerMin, h, iters, cntNodes, cntTris); return;
+            CRT_CASE(0) CRT_CASE(1) CRT_CASE(2) CRT_CASE(3) CRT_CASE(4) CRT_CASE(5) CRT_CASE(6) CRT_CASE(7)
+#undef CRT_CASE
+        }
+    }
+#endif
+    traceClosestOct<COUNT, BLOCK, 8>(nodes, tris, n_nodes, r, tmin, tmax, stack, innerMin, h, iters, cntNodes, cntTris);
+}
+
+template <bool COUNT, int BLOCK>
+__device__ __forceinline__ bool traceAny(const float4* __restrict__ nodes, const float4* __restrict__ tris,
+                                         uint32_t n_nodes, const Ray& r, float tmin, float tmax, Stack& stack, int innerMin,
+                                         uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris)
+{
+#if OCTANT_SPECIALISE
+    const uint32_t oct = octantOf(r);
+    const uint32_t o0 = __builtin_amdgcn_readfirstlane(oct);
+    if (__ballot(oct != o0) == 0ull) {
+        switch (o0) {
+#define CRT_CASE(k) case k: return traceAnyOct<COUNT, BLOCK, k>(nodes, tris, n_nodes, r, tmin, tmax, stack, innerMin, iters, cntNodes, cntTris);
+            CRT_CASE(0) CRT_CASE(1) CRT_CASE(2) CRT_CASE(3) CRT_CASE(4) CRT_CASE(5) CRT_CASE(6) CRT_CASE(7)
+#undef CRT_CASE
+        }
+    }
+#endif
+    return traceAnyOct<COUNT, BLOCK, 8>(nodes, tris, n_nodes, r, tmin, tmax, stack, innerMin, iters, cntNodes, cntTris);
+}
+
+} // namespace
+} // namespace crt
