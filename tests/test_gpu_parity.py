@@ -430,6 +430,14 @@ def test_path_tracing_cornell_all_material_types(pkg, oracle, scenes, renderer):
     got = _compare_path(pkg, oracle, renderer, sc, 200, 120, 3, 5, 42, miss=(0.2, 0.3, 0.4))
     assert np.isfinite(got["rgb"]).all()
     _compare_path(pkg, oracle, renderer, sc, 64, 64, 1, 0, 7)                    # no bounces at all
+    # more samples than one pass of the pipeline carries (16 per 8x8 tile, 4 per 16x16 tile): the sample average must still run
+    # in sample order across the passes (running sums kept in the workgroup's scratch)
+    try:
+        _compare_path(pkg, oracle, renderer, sc, 70, 50, 37, 2, 99)              # passes of 16 + 16 + 5
+        renderer.set_option("path_tile", 16)
+        _compare_path(pkg, oracle, renderer, sc, 70, 50, 9, 2, 5)                # passes of 4 + 4 + 1, macro-tile workgroups
+    finally:
+        renderer.set_option("path_tile", 0)
 
 
 def test_path_tracing_dragon_smooth_normals_and_mirror_ground(pkg, oracle, scenes, dragon, renderer):
