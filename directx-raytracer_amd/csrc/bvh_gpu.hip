@@ -519,8 +519,8 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
             MeshEntry& E = table[m];
             E.triStart = t0; E.vertStart = v0; E.nVerts = M.n_vertices; E.material = static_cast<uint32_t>(M.material_index);
             E.hasNormals = M.normals ? 1u : 0u; E.hasUvs = M.uvs ? 1u : 0u; E.pad0 = E.pad1 = 0;
-            if (M.n_vertices) std::memcpy(&hXyz[3 * static_cast<size_t>(v0)], M.xyz, sizeof(float) * 3 * M.n_vertices);
-            if (M.n_triangles) std::memcpy(&hIdx[3 * static_cast<size_t>(t0)], M.idx, sizeof(uint32_t) * 3 * static_cast<size_t>(M.n_triangles));
+            if (M.n_vertices && M.xyz) std::memcpy(&hXyz[3 * static_cast<size_t>(v0)], M.xyz, sizeof(float) * 3 * M.n_vertices); // (a mesh without triangles may come without arrays)
+            if (M.n_triangles && M.idx) std::memcpy(&hIdx[3 * static_cast<size_t>(t0)], M.idx, sizeof(uint32_t) * 3 * static_cast<size_t>(M.n_triangles));
             if (M.normals && M.n_vertices) std::memcpy(&hNormals[3 * static_cast<size_t>(v0)], M.normals, sizeof(float) * 3 * M.n_vertices);
             if (M.uvs && M.n_vertices) std::memcpy(&hUvs[3 * static_cast<size_t>(v0)], M.uvs, sizeof(float) * 3 * M.n_vertices);
             t0 += M.n_triangles;
