@@ -757,6 +757,20 @@ def test_gpu_bvh_build_matches_its_spec_and_renders_identically(pkg, oracle, sce
                     sah = S.render(cam["position"], cam["matrix"], mode, w, h)
                     for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
                         np.testing.assert_array_equal(got[k], sah[k], err_msg="vs SAH tree, mode %d %s" % (mode, k))
+        # uvs and textures through the device-side gather (the records never exist on the host for this builder)
+        sc = scenes.textured_cornell()
+        cam = sc["camera"]
+        r.upload(sc["meshes"], sc["lights"], sc["materials"], sc["textures"])
+        O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"], build_mode=1, textures=sc["textures"])
+        uv = r.bvh_export_uv()
+        assert uv is not None and uv.tobytes() == O.uvs().tobytes()
+        assert r.bvh_export4q().tobytes() == O.nodes4q().tobytes()
+        r.set_camera(cam["position"], cam["matrix"])
+        r.change_shading_mode(100)
+        got = r.render_frame(320, 240)
+        ref = O.render(cam["position"], cam["matrix"], 100, 320, 240)
+        np.testing.assert_array_equal(got["rgba8"], ref["rgba8"])
+        assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True)
         # switching back to the host SAH builder works on the same context
         r.set_option("gpu_build", 0)
         sc = scenes.cornell_box()
