@@ -28,7 +28,7 @@ NODE4_DTYPE = np.dtype([("minx", "f4", 4), ("maxx", "f4", 4), ("miny", "f4", 4),
                         ("ref", "i4", 4), ("pad", "i4", 4)])
 NODE4Q_DTYPE = np.dtype([("lo", "f4", 3), ("s", "f4", 3), ("qlo_x", "u4"), ("qhi_x", "u4"), ("qlo_y", "u4"), ("qhi_y", "u4"), ("qlo_z", "u4"), ("qhi_z", "u4"), ("ref", "i4", 4)])
 assert NODE4Q_DTYPE.itemsize == 64
-BVH_EMPTY = -0x80000000
+BVH_EMPTY = -1
 TRI_DTYPE = np.dtype([("v0", "f4", 3), ("inst", "u4"), ("e1", "f4", 3), ("prim", "u4"),
                       ("e2", "f4", 3), ("gid", "u4")])
 SHADE_DTYPE = np.dtype([("n0", "f4", 3), ("n1", "f4", 3), ("n2", "f4", 3), ("material", "u4"), ("pad", "u4", 2)])

@@ -58,6 +58,9 @@ constexpr uint32_t kBoostAfter = 300;
 #ifndef LEAF_PAIRS
 #define LEAF_PAIRS 1
 #endif
+#ifndef EARLY_FETCH
+#define EARLY_FETCH 1
+#endif
 #ifndef OCTANT_SPECIALISE
 #define OCTANT_SPECIALISE 1
 #endif // traversal-loop iterations after which a wavefront raises its issue priority
@@ -199,15 +202,15 @@ struct Hit {
 // ---- wide (4-child) node step.  Node = crt_bvh_node4q, 64 bytes = four dwordx4 loads:
 //   {lo.x lo.y lo.z s.x} {s.y s.z qlo_x qhi_x} {qlo_y qhi_y qlo_z qhi_z} {ref[4]}
 // The child planes are 8-bit offsets from the node's own minimum corner (byte k of a q word = child k): plane =
-// fma(q, s, lo).  The vector memory pipe -- per-lane fetch requests -- is what bounds this kernel, not vector arithmetic
-// (30 extra dependent VALU per step measured +0.5 %, one extra 4-byte touch per pushed child +29 %), so the record is
-// kept to four requests per lane instead of the seven of a full-precision node and decoded in registers.  The decode is
+// fma(q, s, lo).  A per-lane fetch request costs this kernel far more than vector arithmetic does (24 / 48 extra dependent
+// VALU per step measured +9 % / +21 %, one extra 4-byte touch per pushed child +29 %; three requests fewer at 48 more VALU
+// was a net -5 %), so the record is kept to four requests per lane instead of the seven of a full-precision node and decoded in registers.  The decode is
 // folded into the slab test: t(q) = fma(q, s * idir, fma(lo, idir, -o * idir)), monotonic in q with the sign of idir, so
 // for a known direction octant (OCT < 8) the near plane of each axis is a fixed member of the (qlo, qhi) pair and the
 // min/max pairs of the generic form (OCT = 8) disappear -- bit for bit the same values.
 // One memory round trip yields four slab tests (15.6 instead of 29.7 steps per ray on the 1M-triangle frame).
-// An unused child slot has ref CRT_BVH_EMPTY (tested explicitly).
-constexpr int kEmptyRef = INT_MIN;
+// An unused child slot is the leaf of no triangles with inverted planes (CRT_BVH_EMPTY): the slab test rejects it, there
+// is no test of the reference (four compares and four mask operations per step less; -1.5 %).
 
 // one wide node in registers; fetched per lane (four dwordx4 vector loads) or, when the whole wavefront stands on the
 // same node, once through the scalar cache (constant address space + wave-uniform address = one s_load_dwordx16)
@@ -226,7 +229,6 @@ __device__ __forceinline__ void slab4(const NodeRegs& nd, const Ray& r, float tm
     const float bx = fmaf(nd.q0.x, r.idir.x, r.noid.x), by = fmaf(nd.q0.y, r.idir.y, r.noid.y), bz = fmaf(nd.q0.z, r.idir.z, r.noid.z);
     const uint32_t lx = __float_as_uint(nd.q1.z), hx = __float_as_uint(nd.q1.w), ly = __float_as_uint(nd.q2.x), hy = __float_as_uint(nd.q2.y),
                    lz = __float_as_uint(nd.q2.z), hz = __float_as_uint(nd.q2.w);
-    const int rf[4] = { nd.refs.x, nd.refs.y, nd.refs.z, nd.refs.w };
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         float t_n, t_f;
@@ -244,7 +246,7 @@ __device__ __forceinline__ void slab4(const NodeRegs& nd, const Ray& r, float tm
             t_f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tcull));
         }
         tn[k] = t_n;
-        hit[k] = (t_n <= t_f) & (rf[k] != kEmptyRef);
+        hit[k] = t_n <= t_f;
     }
 }
 
@@ -285,9 +287,13 @@ __device__ __forceinline__ int pick4(const int4& v, uint32_t i) // v[i], i in 0.
 // closest hit: visit the hit children nearest first.  Order key = (bits(t_near) & 0x7FFFFFFC) | slot: t_near >= 0 so its
 // bit pattern orders like the float, the two low bits hold the slot (keys are unique, order is total and identical in
 // the oracle); misses get 0xFFFFFFFF.  Five min/max pairs sort the four keys.
-template <bool COUNT, int BLOCK, int OCT>
+// EARLY (the step is followed by another node step of the same scheduling decision): the nearest hit child -- or the
+// popped entry of a lane that hit nothing -- is known after two of the network's min levels, so its record is requested
+// right there into ndNext, and the rest of the ordering and the pushes of the other hit children run under that fetch
+// instead of in front of it.  Same stack operations per lane in the same order, so results and counters are unchanged.
+template <bool COUNT, int BLOCK, int OCT, bool EARLY>
 __device__ __forceinline__ void nodeStepClosestAt(const NodeRegs& nd, const Ray& r, float tmin, float tcull, Stack& stack,
-                                                  int& cur, uint32_t& cntNodes)
+                                                  int& cur, uint32_t& cntNodes, const float4* __restrict__ nodes, NodeRegs& ndNext)
 {
     const int4 refs = nd.refs;
     if (COUNT) cntNodes++;
@@ -298,9 +304,24 @@ __device__ __forceinline__ void nodeStepClosestAt(const NodeRegs& nd, const Ray&
 #pragma unroll
     for (int k = 0; k < 4; k++)
         key[k] = hit[k] ? ((__float_as_uint(tn[k]) & 0x7FFFFFFCu) | static_cast<uint32_t>(k)) : 0xFFFFFFFFu;
+#if EARLY_FETCH
+    const uint32_t nearest = min(min(key[0], key[1]), min(key[2], key[3])); // = key[0] after the network
+    const bool any = nearest != 0xFFFFFFFFu;
+    cur = any ? pick4(refs, nearest & 3u) : (stack.sp == 0 ? kDone : stack.pop()); // a lane pops or pushes, never both
+    if (EARLY) {
+        if (cur >= 0) ndNext = loadNode(nodes + kNodeQuads * static_cast<size_t>(cur));
+    }
+#endif
 #define CRT_CSWAP(a, b) { const uint32_t lo = min(key[a], key[b]), hi = max(key[a], key[b]); key[a] = lo; key[b] = hi; }
     CRT_CSWAP(0, 1) CRT_CSWAP(2, 3) CRT_CSWAP(0, 2) CRT_CSWAP(1, 3) CRT_CSWAP(1, 2)
 #undef CRT_CSWAP
+#if EARLY_FETCH
+    if (key[1] != 0xFFFFFFFFu) {
+        if (key[3] != 0xFFFFFFFFu) stack.push(pick4(refs, key[3] & 3u)); // farthest first: the nearest pending child pops first
+        if (key[2] != 0xFFFFFFFFu) stack.push(pick4(refs, key[2] & 3u));
+        stack.push(pick4(refs, key[1] & 3u));
+    }
+#else
     if (key[0] == 0xFFFFFFFFu) {
         cur = stack.sp == 0 ? kDone : stack.pop();
     } else {
@@ -309,12 +330,13 @@ __device__ __forceinline__ void nodeStepClosestAt(const NodeRegs& nd, const Ray&
         if (key[1] != 0xFFFFFFFFu) stack.push(pick4(refs, key[1] & 3u));
         cur = pick4(refs, key[0] & 3u);
     }
+#endif
 }
 
 // any hit: order independent, children taken in slot order
-template <bool COUNT, int BLOCK, int OCT>
+template <bool COUNT, int BLOCK, int OCT, bool EARLY>
 __device__ __forceinline__ void nodeStepAnyAt(const NodeRegs& nd, const Ray& r, float tmin, float tcull, Stack& stack,
-                                              int& cur, uint32_t& cntNodes)
+                                              int& cur, uint32_t& cntNodes, const float4* __restrict__ nodes, NodeRegs& ndNext)
 {
     const int4 refs = nd.refs;
     if (COUNT) cntNodes++;
@@ -322,6 +344,16 @@ __device__ __forceinline__ void nodeStepAnyAt(const NodeRegs& nd, const Ray& r, 
     bool hit[4];
     slab4<OCT>(nd, r, tmin, tcull, tn, hit);
     const bool h0 = hit[0], h1 = hit[1], h2 = hit[2], h3 = hit[3];
+#if EARLY_FETCH
+    cur = h0 ? refs.x : (h1 ? refs.y : (h2 ? refs.z : (h3 ? refs.w : (stack.sp == 0 ? kDone : stack.pop()))));
+    if (EARLY) {
+        if (cur >= 0) ndNext = loadNode(nodes + kNodeQuads * static_cast<size_t>(cur));
+    }
+    // first hit slot became current; later hit slots are pushed, last slot first
+    if (h3 & (h0 | h1 | h2)) stack.push(refs.w);
+    if (h2 & (h0 | h1)) stack.push(refs.z);
+    if (h1 & h0) stack.push(refs.y);
+#else
     if (!(h0 | h1 | h2 | h3)) {
         cur = stack.sp == 0 ? kDone : stack.pop();
     } else {
@@ -331,6 +363,7 @@ __device__ __forceinline__ void nodeStepAnyAt(const NodeRegs& nd, const Ray& r, 
         if (h1 & h0) stack.push(refs.y);
         cur = h0 ? refs.x : (h1 ? refs.y : (h2 ? refs.z : refs.w));
     }
+#endif
 }
 
 // Uniform descent: the rays of an 8x8 packet start at the root and usually agree on the first few nodes.  While every
@@ -342,7 +375,8 @@ __device__ __forceinline__ void nodeStepAnyAt(const NodeRegs& nd, const Ray& r, 
     for (;;) {                                                                                                                 \
         const int c0 = __builtin_amdgcn_readfirstlane(cur);                                                                    \
         if (c0 < 0 || __ballot(cur != c0) != 0ull) break;                                                                      \
-        STEP<COUNT, BLOCK, OCT>(loadNodeUniform(nodes + kNodeQuads * static_cast<size_t>(c0)), r, tmin, tcull, stack, cur, cntNodes);   \
+        NodeRegs ndUnused;                                                                                                     \
+        STEP<COUNT, BLOCK, OCT, false>(loadNodeUniform(nodes + kNodeQuads * static_cast<size_t>(c0)), r, tmin, tcull, stack, cur, cntNodes, nodes, ndUnused);   \
     }
 #else
 #define CRT_UNIFORM_DESCENT(STEP)
@@ -363,19 +397,40 @@ __device__ __forceinline__ void nodeStepAnyAt(const NodeRegs& nd, const Ray& r, 
 // peels the distinct values, fetchers load and ds_write, every lane ds_reads its slot.  Bit-exact, a seventh of the
 // per-lane requests, and 0.49 ms instead of 0.31: the peeling loop and two LDS round trips per step cost far more than
 // the requests they save.)
+// CRT_NODE_STEPS: the NODE_STEPS node steps of one scheduling decision.  The first fetches its record here; with
+// EARLY_FETCH every step but the last requests the next record itself (see nodeStepClosestAt), per lane.
 #if UNIFORM_STEP
-#define CRT_NODE_STEP(STEP)                                                                                                    \
+#define CRT_FIRST_NODE_STEP(STEP, EARLY)                                                                                       \
     {                                                                                                                          \
         const int c0 = __builtin_amdgcn_readfirstlane(cur);                                                                    \
         if (__ballot(cur != c0) == 0ull) {                                                                                     \
-            STEP<COUNT, BLOCK, OCT>(loadNodeUniform(nodes + kNodeQuads * static_cast<size_t>(c0)), r, tmin, tcull, stack, cur, cntNodes); \
+            STEP<COUNT, BLOCK, OCT, EARLY>(loadNodeUniform(nodes + kNodeQuads * static_cast<size_t>(c0)), r, tmin, tcull, stack, cur, cntNodes, nodes, ndNext); \
         } else {                                                                                                               \
             CRT_DIV_STATS_NODE                                                                                                 \
-            STEP<COUNT, BLOCK, OCT>(loadNode(nodes + kNodeQuads * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);     \
+            STEP<COUNT, BLOCK, OCT, EARLY>(loadNode(nodes + kNodeQuads * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes, nodes, ndNext);     \
         }                                                                                                                      \
     }
 #else
-#define CRT_NODE_STEP(STEP) STEP<COUNT, BLOCK, OCT>(loadNode(nodes + kNodeQuads * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes);
+#define CRT_FIRST_NODE_STEP(STEP, EARLY) STEP<COUNT, BLOCK, OCT, EARLY>(loadNode(nodes + kNodeQuads * static_cast<size_t>(cur)), r, tmin, tcull, stack, cur, cntNodes, nodes, ndNext);
+#endif
+#if EARLY_FETCH
+#define CRT_NODE_STEPS(STEP)                                                                                                   \
+    if (cur >= 0) {                                                                                                            \
+        NodeRegs ndNext;                                                                                                       \
+        CRT_FIRST_NODE_STEP(STEP, (NODE_STEPS > 1))                                                                            \
+        _Pragma("unroll") for (int rep = 1; rep < NODE_STEPS; rep++) {                                                         \
+            if (cur >= 0) {                                                                                                    \
+                const NodeRegs ndCur = ndNext;                                                                                 \
+                if (rep + 1 < NODE_STEPS) STEP<COUNT, BLOCK, OCT, true>(ndCur, r, tmin, tcull, stack, cur, cntNodes, nodes, ndNext);   \
+                else STEP<COUNT, BLOCK, OCT, false>(ndCur, r, tmin, tcull, stack, cur, cntNodes, nodes, ndNext);               \
+            }                                                                                                                  \
+        }                                                                                                                      \
+    }
+#else
+#define CRT_NODE_STEPS(STEP)                                                                                                   \
+    _Pragma("unroll") for (int rep = 0; rep < NODE_STEPS; rep++) {                                                             \
+        if (cur >= 0) { NodeRegs ndNext; CRT_FIRST_NODE_STEP(STEP, false) }                                                    \
+    }
 #endif
 
 // Wave-level scheduling shared by both traversals.  Every lane walks its own ray in its own fixed order (so results
@@ -400,10 +455,7 @@ __device__ __forceinline__ bool closestIteration(const float4* __restrict__ node
 #if CRT_PROF
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-#pragma unroll
-        for (int rep = 0; rep < NODE_STEPS; rep++) { // several node steps per scheduling decision: fewer ballots/branches
-            if (cur >= 0) CRT_NODE_STEP(nodeStepClosestAt)
-        }
+        CRT_NODE_STEPS(nodeStepClosestAt) // several node steps per scheduling decision: fewer ballots/branches
 #if CRT_PROF
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         stack.tNode += __builtin_amdgcn_s_memtime() - ts0; stack.itNode++; stack.lanesNode += __popcll(innerMask);
@@ -515,10 +567,7 @@ __device__ __forceinline__ bool anyIteration(const float4* __restrict__ nodes, c
 #if CRT_PROF
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
-#pragma unroll
-        for (int rep = 0; rep < NODE_STEPS; rep++) {
-            if (cur >= 0) CRT_NODE_STEP(nodeStepAnyAt)
-        }
+        CRT_NODE_STEPS(nodeStepAnyAt) // several node steps per scheduling decision: fewer ballots/branches
 #if CRT_PROF
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         stack.tNode += __builtin_amdgcn_s_memtime() - ts0; stack.itNode++; stack.lanesNode += __popcll(innerMask);

@@ -80,8 +80,10 @@ typedef struct crt_bvh_node {
     int32_t pad0, pad1;
 } crt_bvh_node;
 /* 128-byte wide node (full-precision child boxes; the builders' output, host side): up to 4 children, planes stored per axis across the children; collapsed from
- * the binary tree above. ref >= 0: wide node index; CRT_BVH_EMPTY: unused slot; other negatives: leaf (as above) */
-#define CRT_BVH_EMPTY ((int32_t)0x80000000)
+ * the binary tree above. ref >= 0: wide node index; negative: leaf (as above).  An unused slot is CRT_BVH_EMPTY = the leaf
+ * of no triangles (~0) with an inverted box: traversal has no separate test for it -- the inverted box is simply missed
+ * (and were a degenerate, point-sized node ever to 'hit' it, a leaf without triangles is what the ray would visit). */
+#define CRT_BVH_EMPTY ((int32_t)-1)
 typedef struct crt_bvh_node4 {
     float minx[4], maxx[4], miny[4], maxy[4], minz[4], maxz[4];
     int32_t ref[4];
@@ -92,7 +94,8 @@ typedef struct crt_bvh_node4 {
  * [fma(qlo_a.byte[k], s_a, lo_a), fma(qhi_a.byte[k], s_a, lo_a)], rounded outwards (it always contains the full-precision
  * box of crt_bvh_node4), so traversal results are unchanged and only the fetch counts differ by a percent or two.
  * Derived from crt_bvh_node4 by a fixed rule (DESIGN.md "Quantised nodes"; csrc/bvh_build.cpp quantizeBvh4 and the
- * oracle's restatement agree byte for byte).  Unused slots: ref = CRT_BVH_EMPTY, qlo = 255, qhi = 0. */
+ * oracle's restatement agree byte for byte).  Unused slots: ref = CRT_BVH_EMPTY, qlo = 255, qhi = 0 (decoded max < min on
+ * every axis with extent, so the slab test rejects them like any other missed child). */
 typedef struct crt_bvh_node4q {
     float lo[3];
     float s[3];

@@ -898,8 +898,7 @@ static inline int slab4(const oracle_node4q* N, const ray* r, float tmin, float 
     const __m128 tn = _mm_max_ps(_mm_max_ps(_mm_min_ps(x0, x1), _mm_min_ps(y0, y1)), _mm_max_ps(_mm_min_ps(z0, z1), _mm_set1_ps(tmin)));
     const __m128 tf = _mm_min_ps(_mm_min_ps(_mm_max_ps(x0, x1), _mm_max_ps(y0, y1)), _mm_min_ps(_mm_max_ps(z0, z1), _mm_set1_ps(tcull)));
     _mm_storeu_ps(tn_out, tn);
-    const __m128i empty = _mm_cmpeq_epi32(_mm_loadu_si128((const __m128i*)N->ref), _mm_set1_epi32((int)ORACLE_EMPTY));
-    return _mm_movemask_ps(_mm_andnot_ps(_mm_castsi128_ps(empty), _mm_cmple_ps(tn, tf)));
+    return _mm_movemask_ps(_mm_cmple_ps(tn, tf)); /* unused slots carry inverted planes: no test of their own */
 }
 
 static inline int wide_step(const oracle_node4q* N, const ray* r, float tmin, float tcull, uint32_t key[4])

@@ -44,8 +44,9 @@ typedef struct oracle_node {
 } oracle_node;
 
 /* 128-byte wide node: up to four children, planes stored per axis across the children (SoA). Built by collapsing the
- * binary tree (DESIGN.md "BVH4"). ref >= 0: wide node index; ORACLE_EMPTY: unused slot; other negatives: leaf as above. */
-#define ORACLE_EMPTY ((int32_t)0x80000000)
+ * binary tree (DESIGN.md "BVH4"). ref >= 0: wide node index; negative: leaf as above; unused slot: ORACLE_EMPTY = the leaf of no
+ * triangles with an inverted box (rejected by the slab test, never by a test of its own). */
+#define ORACLE_EMPTY ((int32_t)-1)
 typedef struct oracle_node4 {
     float minx[4], maxx[4], miny[4], maxy[4], minz[4], maxz[4];
     int32_t ref[4];

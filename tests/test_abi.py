@@ -29,7 +29,7 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_struct_sizes_match_header(pkg):
     assert pkg.NODE_DTYPE.itemsize == 64 and pkg.TRI_DTYPE.itemsize == 48 and pkg.SHADE_DTYPE.itemsize == 48
-    assert pkg.NODE4_DTYPE.itemsize == 128 and pkg.BVH_EMPTY == -0x80000000
+    assert pkg.NODE4_DTYPE.itemsize == 128 and pkg.BVH_EMPTY == -1
     assert ctypes.sizeof(pkg.MeshView) == 48 and ctypes.sizeof(pkg.Light) == 16 and ctypes.sizeof(pkg.Material) == 28
     assert ctypes.sizeof(pkg.Texture) == 56 and pkg.UV_DTYPE.itemsize == 24
     assert ctypes.sizeof(pkg.FrameStats) == 48

@@ -59,7 +59,7 @@ def _check_wide(nodes, nodes4, depth4, tris):
     if len(nodes) == 0:
         assert len(nodes4) == 0
         return
-    EMPTY = -0x80000000
+    EMPTY = -1
     seen = np.zeros(len(tris), dtype=np.int32)
     order, stack, deepest = [], [(0, 1)], 0
     while stack:
@@ -69,7 +69,8 @@ def _check_wide(nodes, nodes4, depth4, tris):
         n = nodes4[i]
         refs = [int(r) for r in n["ref"]]
         used = [r for r in refs if r != EMPTY]
-        assert 2 <= len(used) <= 4 and refs[:len(used)] == used, "empty slots trail"
+        # (a scene of one leaf is wrapped in a node whose second child is the leaf of no triangles = the unused-slot marker)
+        assert (1 if len(nodes4) == 1 else 2) <= len(used) <= 4 and refs[:len(used)] == used, "empty slots trail"
         for k in reversed(range(len(used))):
             r = used[k]
             assert n["minx"][k] <= n["maxx"][k] and n["miny"][k] <= n["maxy"][k] and n["minz"][k] <= n["maxz"][k]
@@ -92,7 +93,7 @@ def _check_quantised(nodes4, q):
     assert len(q) == len(nodes4)
     if len(q) == 0:
         return
-    EMPTY = -0x80000000
+    EMPTY = -1
     np.testing.assert_array_equal(q["ref"], nodes4["ref"])
     used = nodes4["ref"] != EMPTY
     for a, (qlo, qhi, mn, mx) in enumerate((("qlo_x", "qhi_x", "minx", "maxx"), ("qlo_y", "qhi_y", "miny", "maxy"), ("qlo_z", "qhi_z", "minz", "maxz"))):
