@@ -67,7 +67,7 @@ CRT_HD inline int wideSlots(const crt_bvh_node* nodes, int32_t b, uint32_t depth
     return n;
 }
 
-// the wide node of n slots, inner refs still binary indices; unused slots: an inverted box and CRT_BVH_EMPTY
+// the wide node of n slots, inner refs still binary indices; unused slots: an inverted box and CRT_BVH_EMPTY (quantised: a point)
 CRT_HD inline void fillWide(const WideSlot sl[4], int n, crt_bvh_node4& W)
 {
     for (int i = 0; i < 4; i++) {
@@ -120,8 +120,8 @@ CRT_HD inline void quantizeNode4(const crt_bvh_node4& W, crt_bvh_node4q& Q)
         Q.s[a] = s;
         for (int k = 0; k < 4; k++) {
             uint32_t l = 0, h = 255;
-            if (W.ref[k] == CRT_BVH_EMPTY) {
-                l = 255;
+            if (W.ref[k] == CRT_BVH_EMPTY) { // a point at the node's minimum corner (crt_hip.h)
+                l = 0;
                 h = 0;
             } else if (valid[k]) {
                 const float fl = (mins[a][k] - lo) / s, fh = (maxs[a][k] - lo) / s;

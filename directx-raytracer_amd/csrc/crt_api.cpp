@@ -85,6 +85,7 @@ struct crt_ctx {
     // quarters start first, while the chip is full, and trace their shadow rays at a quarter of the lane efficiency); the
     // rank-share latency at 8 ranks moves from 188 to 182 us only: a packet's chain of dependent steps is its slowest RAY's
     uint32_t tuneSplitUnits = 0;
+    bool tuneXcdAffine = false;
     uint32_t debugSkipUnits = 0;
     hipStream_t lastRenderStream = nullptr;
     bool haveLastRenderStream = false;
@@ -354,7 +355,7 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
     if (feedback) {
         hipStream_t ss = c->sideStream;
         HIP_TRY(c, hipStreamWaitEvent(ss, c->evRender[slot], 0));
-        const int rs = crt::launchSortUnits(c->dUnitCost[slot], c->dUnitOrder[slot], nUnits, ss);
+        const int rs = crt::launchSortUnits(c->dUnitCost[slot], c->dUnitOrder[slot], nUnits, c->tuneXcdAffine, ss);
         if (rs != 0) return fail(c, CRT_EHIP, "sort kernel launch failed: %s", hipGetErrorString(static_cast<hipError_t>(rs)));
         HIP_TRY(c, hipEventRecord(c->evSort[slot], ss));
         c->sortPending[slot] = true;
@@ -728,6 +729,11 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
     }
     if (std::strcmp(name, "xcd_group") == 0 && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) {
         c->tuneXcdGroup = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "xcd_affine_order") == 0 && (value == 0 || value == 1)) {
+        c->tuneXcdAffine = value != 0;
+        for (int i = 0; i < crt_ctx::kRing; i++) c->orderKey[i] = 0; // orders sorted the other way are stale
         return CRT_OK;
     }
     if (std::strcmp(name, "split_units") == 0 && value >= 0 && value <= 65536) {

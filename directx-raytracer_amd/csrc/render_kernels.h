@@ -80,7 +80,7 @@ int launchPath(const RenderParams& p, bool counting, ihipStream_t* stream);
 size_t pathRegionBytes(uint32_t tile, uint32_t samples_per_pass);
 uint32_t pathWorkgroupCount(const RenderParams& p);
 // unit_cost -> unit_order (descending)
-int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, ihipStream_t* stream);
+int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, bool xcdAffine, ihipStream_t* stream);
 // tile-major gathered buffer -> row-major frame
 int launchUntile(const uint32_t* gathered, uint32_t* frame, uint32_t width, uint32_t height, uint32_t n_ranks,
                  uint32_t rank_stride, uint32_t first_slot, ihipStream_t* stream);

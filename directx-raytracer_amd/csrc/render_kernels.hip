@@ -286,9 +286,88 @@ __global__ __launch_bounds__(kSortThreads) void sortUnitsKernel(const uint32_t* 
     for (uint32_t i = t; i < n; i += kSortThreads) order[atomicAdd(&hist[min(cost[i], kSortBuckets - 1u)], 1u)] = i;
 }
 
-int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, ihipStream_t* stream)
+// XCD-affine launch order.  Workgroup b runs on XCD b % 8, and each XCD has its own L2: the unit list (which walks the frame
+// in 64x64-pixel blocks) is cut into eight contiguous regions of equal total cost, each region is sorted by descending cost,
+// and the j-th unit of region x is launched at position 8 j + x -- so an XCD keeps working inside one part of the frame (and
+// of the scene) while every XCD still starts with its own most expensive packets.  Regions hold different numbers of units;
+// the cheapest units of the longer regions fill the last rounds of the shorter ones, so the order stays a permutation of
+// 0..n-1 (n is a multiple of 512).  Region boundaries fall on multiples of n / 256 units.
+__global__ __launch_bounds__(kSortThreads) void sortUnitsAffineKernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n)
 {
-    hipLaunchKernelGGL(sortUnitsKernel, dim3(1), dim3(kSortThreads), 0, stream, cost, order, n);
+    __shared__ uint32_t hist[8 * kSortBuckets];
+    __shared__ uint32_t sums[kSortThreads];
+    __shared__ uint32_t chunkRegion[kSortThreads];
+    __shared__ uint32_t cnt[8], surplusBase[8], deficitBase[8], deficit[8];
+    const uint32_t t = threadIdx.x;
+    const uint32_t chunk = n / kSortThreads, rounds = n / 8u;
+    for (uint32_t b = t; b < 8u * kSortBuckets; b += kSortThreads) hist[b] = 0;
+    uint32_t mine = 0;
+    for (uint32_t i = t * chunk; i < (t + 1u) * chunk; i++) mine += cost[i];
+    sums[t] = mine;
+    __syncthreads();
+    for (uint32_t d = 1; d < kSortThreads; d <<= 1) {
+        const uint32_t add = t >= d ? sums[t - d] : 0u;
+        __syncthreads();
+        sums[t] += add;
+        __syncthreads();
+    }
+    const uint32_t total = sums[kSortThreads - 1u];
+    {
+        const unsigned long long mid = static_cast<unsigned long long>(sums[t] - mine) + mine / 2u;
+        const uint32_t r = total ? static_cast<uint32_t>(mid * 8ull / total) : t / (kSortThreads / 8u);
+        chunkRegion[t] = r < 7u ? r : 7u;
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += kSortThreads) atomicAdd(&hist[chunkRegion[i / chunk] * kSortBuckets + min(cost[i], kSortBuckets - 1u)], 1u);
+    __syncthreads();
+    // per region: most expensive bucket first; 32 threads per region, 32 reversed buckets each
+    const uint32_t reg = t >> 5, sub = t & 31u;
+    uint32_t tot = 0;
+    for (uint32_t k = 0; k < 32u; k++) tot += hist[reg * kSortBuckets + kSortBuckets - 1u - (sub * 32u + k)];
+    __syncthreads();
+    sums[t] = tot;
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t k = 0; k < sub; k++) base += sums[reg * 32u + k];
+    if (sub == 31u) cnt[reg] = base + tot;
+    for (uint32_t k = 0; k < 32u; k++) {
+        uint32_t& h = hist[reg * kSortBuckets + kSortBuckets - 1u - (sub * 32u + k)];
+        const uint32_t c = h;
+        h = base;
+        base += c;
+    }
+    __syncthreads();
+    if (t == 0) {
+        uint32_t sb = 0, db = 0;
+        for (uint32_t x = 0; x < 8u; x++) {
+            surplusBase[x] = sb;
+            deficitBase[x] = db;
+            sb += cnt[x] > rounds ? cnt[x] - rounds : 0u;
+            deficit[x] = cnt[x] < rounds ? rounds - cnt[x] : 0u;
+            db += deficit[x];
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += kSortThreads) {
+        const uint32_t x = chunkRegion[i / chunk];
+        const uint32_t j = atomicAdd(&hist[x * kSortBuckets + min(cost[i], kSortBuckets - 1u)], 1u);
+        uint32_t pos;
+        if (j < rounds) {
+            pos = j * 8u + x;
+        } else {
+            const uint32_t sidx = surplusBase[x] + (j - rounds);
+            uint32_t y = 0;
+            while (y < 7u && sidx >= deficitBase[y] + deficit[y]) y++;
+            pos = (cnt[y] + (sidx - deficitBase[y])) * 8u + y;
+        }
+        order[pos] = i;
+    }
+}
+
+int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, bool xcdAffine, ihipStream_t* stream)
+{
+    if (xcdAffine && n % (2u * kSortThreads) == 0u) hipLaunchKernelGGL(sortUnitsAffineKernel, dim3(1), dim3(kSortThreads), 0, stream, cost, order, n);
+    else hipLaunchKernelGGL(sortUnitsKernel, dim3(1), dim3(kSortThreads), 0, stream, cost, order, n);
     return static_cast<int>(hipGetLastError());
 }
 

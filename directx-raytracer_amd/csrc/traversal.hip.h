@@ -209,8 +209,9 @@ struct Hit {
 // for a known direction octant (OCT < 8) the near plane of each axis is a fixed member of the (qlo, qhi) pair and the
 // min/max pairs of the generic form (OCT = 8) disappear -- bit for bit the same values.
 // One memory round trip yields four slab tests (15.6 instead of 29.7 steps per ray on the 1M-triangle frame).
-// An unused child slot is the leaf of no triangles with inverted planes (CRT_BVH_EMPTY): the slab test rejects it, there
-// is no test of the reference (four compares and four mask operations per step less; -1.5 %).
+// An unused child slot is the leaf of no triangles with a point box (CRT_BVH_EMPTY, qlo = qhi = 0): the slab test rejects
+// it, there is no test of the reference (four compares and four mask operations per step less; -1.5 %).  (Not an inverted
+// box: the min/max form of the mixed-octant path would turn that into the whole node and visit the empty leaf every time.)
 
 // one wide node in registers; fetched per lane (four dwordx4 vector loads) or, when the whole wavefront stands on the
 // same node, once through the scalar cache (constant address space + wave-uniform address = one s_load_dwordx16)

@@ -81,8 +81,9 @@ typedef struct crt_bvh_node {
 } crt_bvh_node;
 /* 128-byte wide node (full-precision child boxes; the builders' output, host side): up to 4 children, planes stored per axis across the children; collapsed from
  * the binary tree above. ref >= 0: wide node index; negative: leaf (as above).  An unused slot is CRT_BVH_EMPTY = the leaf
- * of no triangles (~0) with an inverted box: traversal has no separate test for it -- the inverted box is simply missed
- * (and were a degenerate, point-sized node ever to 'hit' it, a leaf without triangles is what the ray would visit). */
+ * of no triangles (~0); here its box is inverted (+inf, -inf), in the quantised node it is a single point.  Traversal has no
+ * separate test for it: a ray misses the point like any other box it does not pass through, and a ray that did pass exactly
+ * through it would visit a leaf without triangles. */
 #define CRT_BVH_EMPTY ((int32_t)-1)
 typedef struct crt_bvh_node4 {
     float minx[4], maxx[4], miny[4], maxy[4], minz[4], maxz[4];
@@ -94,8 +95,8 @@ typedef struct crt_bvh_node4 {
  * [fma(qlo_a.byte[k], s_a, lo_a), fma(qhi_a.byte[k], s_a, lo_a)], rounded outwards (it always contains the full-precision
  * box of crt_bvh_node4), so traversal results are unchanged and only the fetch counts differ by a percent or two.
  * Derived from crt_bvh_node4 by a fixed rule (DESIGN.md "Quantised nodes"; csrc/bvh_build.cpp quantizeBvh4 and the
- * oracle's restatement agree byte for byte).  Unused slots: ref = CRT_BVH_EMPTY, qlo = 255, qhi = 0 (decoded max < min on
- * every axis with extent, so the slab test rejects them like any other missed child). */
+ * oracle's restatement agree byte for byte).  Unused slots: ref = CRT_BVH_EMPTY, qlo = qhi = 0: the point at the node's minimum
+ * corner (a valid box, so the min/max form of the slab test and the octant-specialised one agree on it as on any other). */
 typedef struct crt_bvh_node4q {
     float lo[3];
     float s[3];
@@ -218,6 +219,8 @@ int crt_render_frame_distributed(crt_ctx* ctx, uint32_t width, uint32_t height, 
  * packets of the previous frame first: 0 never, 1 always, 2 = default: only for a frame issued on the same stream as the frame
  * before, where frames run one after another), "remeasure_every" (a moving camera re-measures packet costs every n-th use of a scratch slot; default 1), "boost_units",
  * "split_units" (with a launch order: the n most expensive 8x8 packets are rendered as four 4x4 quarters; default 0 = off),
+ * "xcd_affine_order" 0/1 (with a launch order: the frame is cut into eight regions of equal cost, one per XCD and its L2, each launched
+ * most expensive packet first; default 0 -- primary rays alone gain 5 %, a shaded frame loses 1 %),
  * "path_tile" (mode 200 work split: pixel-tile edge per workgroup, 8 (default, also 0) or 16), "stack_entries" (0 = default 16; deeper entries spill to a
  * global arena). The diagnostic options "timeline", "debug_skip_units" and "debug_force_measure" (which do change what a frame
  * does) exist only in the diagnostic build of the library (tools/diag_build.sh); the product returns CRT_EINVAL for them. */

@@ -348,8 +348,8 @@ static void quantize_node4(const oracle_node4* W, oracle_node4q* Q)
         Q->s[a] = sc;
         for (int k = 0; k < 4; k++) {
             uint32_t l = 0, h = 255;
-            if (W->ref[k] == ORACLE_EMPTY) {
-                l = 255;
+            if (W->ref[k] == ORACLE_EMPTY) { /* a point at the node's minimum corner: see crt_oracle.h */
+                l = 0;
                 h = 0;
             } else if (valid[k]) {
                 const float fl = (mins[a][k] - lo) / sc, fh = (maxs[a][k] - lo) / sc;
@@ -898,7 +898,7 @@ static inline int slab4(const oracle_node4q* N, const ray* r, float tmin, float 
     const __m128 tn = _mm_max_ps(_mm_max_ps(_mm_min_ps(x0, x1), _mm_min_ps(y0, y1)), _mm_max_ps(_mm_min_ps(z0, z1), _mm_set1_ps(tmin)));
     const __m128 tf = _mm_min_ps(_mm_min_ps(_mm_max_ps(x0, x1), _mm_max_ps(y0, y1)), _mm_min_ps(_mm_max_ps(z0, z1), _mm_set1_ps(tcull)));
     _mm_storeu_ps(tn_out, tn);
-    return _mm_movemask_ps(_mm_cmple_ps(tn, tf)); /* unused slots carry inverted planes: no test of their own */
+    return _mm_movemask_ps(_mm_cmple_ps(tn, tf)); /* unused slots are point boxes: no test of their own */
 }
 
 static inline int wide_step(const oracle_node4q* N, const ray* r, float tmin, float tcull, uint32_t key[4])

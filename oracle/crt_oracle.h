@@ -45,7 +45,8 @@ typedef struct oracle_node {
 
 /* 128-byte wide node: up to four children, planes stored per axis across the children (SoA). Built by collapsing the
  * binary tree (DESIGN.md "BVH4"). ref >= 0: wide node index; negative: leaf as above; unused slot: ORACLE_EMPTY = the leaf of no
- * triangles with an inverted box (rejected by the slab test, never by a test of its own). */
+ * triangles; inverted box here, the point at the node's minimum corner in the quantised node (missed by the slab test like
+ * any box the ray does not pass through; never a test of its own). */
 #define ORACLE_EMPTY ((int32_t)-1)
 typedef struct oracle_node4 {
     float minx[4], maxx[4], miny[4], maxy[4], minz[4], maxz[4];

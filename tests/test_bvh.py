@@ -109,7 +109,7 @@ def _check_quantised(nodes4, q):
             assert np.all(dec_lo[fin] <= nodes4[mn][:, k][fin]) and np.all(dec_hi[fin] >= nodes4[mx][:, k][fin]), "quantised box must contain the exact one"
             slack = 2.0 * s[fin] + 1e-6 * (np.abs(lo[fin]) + 255.0 * s[fin])
             assert np.all(nodes4[mn][:, k][fin] - dec_lo[fin] <= slack) and np.all(dec_hi[fin] - nodes4[mx][:, k][fin] <= slack), "and be tight to two quanta"
-            assert np.all(l[~u] == 255) and np.all(h[~u] == 0)
+            assert np.all(l[~u] == 0) and np.all(h[~u] == 0)  # a point at the node's minimum corner
 
 
 def _compare(pkg, oracle, meshes):

@@ -16,7 +16,8 @@ def main():
     r.change_shading_mode(int(sys.argv[1]) if len(sys.argv) > 1 else 100)
     W, H = 1920, 1080
     frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
-    for _ in range(3):
+    if os.environ.get("CRT_AFFINE"): r.set_option("xcd_affine_order", int(os.environ["CRT_AFFINE"]))
+    for _ in range(14):
         r.render_frame_device(W, H, frame.data_ptr(), stats=True)
     r.set_option("timeline", 1)
     st = r.render_frame_device(W, H, frame.data_ptr(), stats=True)
