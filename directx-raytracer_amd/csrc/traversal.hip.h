@@ -230,22 +230,17 @@ __device__ __forceinline__ void slab4(const NodeRegs& nd, const Ray& r, float tm
     const float bx = fmaf(nd.q0.x, r.idir.x, r.noid.x), by = fmaf(nd.q0.y, r.idir.y, r.noid.y), bz = fmaf(nd.q0.z, r.idir.z, r.noid.z);
     const uint32_t lx = __float_as_uint(nd.q1.z), hx = __float_as_uint(nd.q1.w), ly = __float_as_uint(nd.q2.x), hy = __float_as_uint(nd.q2.y),
                    lz = __float_as_uint(nd.q2.z), hz = __float_as_uint(nd.q2.w);
+    // near / far member of each (qlo, qhi) pair: fixed by the template octant, or picked per lane from the direction's sign
+    // bits (mixed-octant wavefronts: bounce rays) -- six selects instead of the twelve min/max of the textbook form, and
+    // the same values: t is monotonic in q with the sign of idir
+    const bool sx = (OCT < 8) ? (OCT & 1) != 0 : (__float_as_uint(r.d.x) >> 31) != 0u;
+    const bool sy = (OCT < 8) ? (OCT & 2) != 0 : (__float_as_uint(r.d.y) >> 31) != 0u;
+    const bool sz = (OCT < 8) ? (OCT & 4) != 0 : (__float_as_uint(r.d.z) >> 31) != 0u;
+    const uint32_t nxw = sx ? hx : lx, fxw = sx ? lx : hx, nyw = sy ? hy : ly, fyw = sy ? ly : hy, nzw = sz ? hz : lz, fzw = sz ? lz : hz;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        float t_n, t_f;
-        if (OCT < 8) {
-            const float nx = ubyteToFloat((OCT & 1) ? hx : lx, k), fx = ubyteToFloat((OCT & 1) ? lx : hx, k);
-            const float ny = ubyteToFloat((OCT & 2) ? hy : ly, k), fy = ubyteToFloat((OCT & 2) ? ly : hy, k);
-            const float nz = ubyteToFloat((OCT & 4) ? hz : lz, k), fz = ubyteToFloat((OCT & 4) ? lz : hz, k);
-            t_n = fmaxf(fmaxf(fmaf(nx, ax, bx), fmaf(ny, ay, by)), fmaxf(fmaf(nz, az, bz), tmin));
-            t_f = fminf(fminf(fmaf(fx, ax, bx), fmaf(fy, ay, by)), fminf(fmaf(fz, az, bz), tcull));
-        } else {
-            const float x0 = fmaf(ubyteToFloat(lx, k), ax, bx), x1 = fmaf(ubyteToFloat(hx, k), ax, bx);
-            const float y0 = fmaf(ubyteToFloat(ly, k), ay, by), y1 = fmaf(ubyteToFloat(hy, k), ay, by);
-            const float z0 = fmaf(ubyteToFloat(lz, k), az, bz), z1 = fmaf(ubyteToFloat(hz, k), az, bz);
-            t_n = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-            t_f = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tcull));
-        }
+        const float t_n = fmaxf(fmaxf(fmaf(ubyteToFloat(nxw, k), ax, bx), fmaf(ubyteToFloat(nyw, k), ay, by)), fmaxf(fmaf(ubyteToFloat(nzw, k), az, bz), tmin));
+        const float t_f = fminf(fminf(fmaf(ubyteToFloat(fxw, k), ax, bx), fmaf(ubyteToFloat(fyw, k), ay, by)), fminf(fmaf(ubyteToFloat(fzw, k), az, bz), tcull));
         tn[k] = t_n;
         hit[k] = t_n <= t_f;
     }
