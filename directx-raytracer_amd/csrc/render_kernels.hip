@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kSortThreads) void sortUnitsKernel(const uint32_t* 
 // and the j-th unit of region x is launched at position 8 j + x -- so an XCD keeps working inside one part of the frame (and
 // of the scene) while every XCD still starts with its own most expensive packets.  Regions hold different numbers of units;
 // the cheapest units of the longer regions fill the last rounds of the shorter ones, so the order stays a permutation of
-// 0..n-1 (n is a multiple of 512).  Region boundaries fall on multiples of n / 256 units.
+// 0..n-1 (n is a multiple of 512); 'equal cost' therefore means equal cost above that of such a filler unit.  Region boundaries fall on multiples of n / 256 units.
 __global__ __launch_bounds__(kSortThreads) void sortUnitsAffineKernel(const uint32_t* __restrict__ cost, uint32_t* __restrict__ order, uint32_t n)
 {
     __shared__ uint32_t hist[8 * kSortBuckets];
@@ -300,9 +300,23 @@ __global__ __launch_bounds__(kSortThreads) void sortUnitsAffineKernel(const uint
     __shared__ uint32_t cnt[8], surplusBase[8], deficitBase[8], deficit[8];
     const uint32_t t = threadIdx.x;
     const uint32_t chunk = n / kSortThreads, rounds = n / 8u;
+    __shared__ uint32_t fillCost;
     for (uint32_t b = t; b < 8u * kSortBuckets; b += kSortThreads) hist[b] = 0;
+    __syncthreads();
+    // Every XCD runs exactly n / 8 units, so a region with fewer units than that is topped up with the cheapest units of the
+    // frame, of cost ~ fillCost each (the 1/16 quantile): what has to be equal across the regions is the cost above that.
+    for (uint32_t i = t; i < n; i += kSortThreads) atomicAdd(&hist[min(cost[i], kSortBuckets - 1u)], 1u);
+    __syncthreads();
+    if (t == 0) {
+        uint32_t acc = 0, b = 0;
+        while (b + 1u < kSortBuckets && acc + hist[b] < n / 16u) acc += hist[b++];
+        fillCost = b;
+    }
+    __syncthreads();
+    for (uint32_t b = t; b < kSortBuckets; b += kSortThreads) hist[b] = 0;
+    const uint32_t fc = fillCost;
     uint32_t mine = 0;
-    for (uint32_t i = t * chunk; i < (t + 1u) * chunk; i++) mine += cost[i];
+    for (uint32_t i = t * chunk; i < (t + 1u) * chunk; i++) mine += cost[i] > fc ? cost[i] - fc : 0u;
     sums[t] = mine;
     __syncthreads();
     for (uint32_t d = 1; d < kSortThreads; d <<= 1) {

@@ -9,11 +9,13 @@ def main():
     import __graft_entry__ as entry
     ap = argparse.ArgumentParser(); ap.add_argument("libs", nargs="+"); ap.add_argument("--mode", type=int, default=100)
     ap.add_argument("--opt", default=None, help="name=v1,v2,...: also sweep a crt_set_option knob for every library")
+    ap.add_argument("--scene", default="heightfield", help="heightfield (C3) | heightfield5m | soup")
     ap.add_argument("--rounds", type=int, default=6); ap.add_argument("--frames", type=int, default=20)
     a = ap.parse_args()
     import torch
     pkg = entry.load_package(); scenes = importlib.import_module(entry.PKG_NAME + ".scenes")
-    sc = scenes.heightfield(n_lights=1)
+    sc = {"heightfield": lambda: scenes.heightfield(n_lights=1), "heightfield5m": lambda: scenes.heightfield(n=1581, n_lights=1),
+          "soup": scenes.icosphere_soup}[a.scene]()
     W, H = 1920, 1080
     frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
     rs = []
