@@ -19,6 +19,20 @@ namespace {
 
 // PHONG: the specular term of mode 100 is compiled into its own variant (chosen at launch when "phong_ks" is non-zero), so
 // that the plain Lambert kernel keeps its register budget
+// pixel of a lane inside its 16x16 macro tile: 8x8 packet `wave`, or one 4x4 quarter of it (lanes 0..15)
+__device__ __forceinline__ void lanePixel(uint32_t wave, uint32_t quarter, uint32_t lane, uint32_t& lx, uint32_t& ly)
+{
+    lx = (wave & 1u) * 8u;
+    ly = (wave >> 1) * 8u;
+    if (quarter < 4u) { // lanes 0..15 walk the 4x4 quarter, the others have nothing to do
+        lx += (quarter & 1u) * 4u + (lane & 3u);
+        ly += (quarter >> 1) * 4u + ((lane >> 2) & 3u);
+    } else {
+        lx += lane & 7u;
+        ly += lane >> 3;
+    }
+}
+
 template <bool COUNT, bool PHONG>
 __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const RenderParams p)
 {
@@ -93,14 +107,8 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
     }
 
     const uint32_t tid = threadIdx.x, wave = unit & 3u, lane = tid & 63u;
-    uint32_t lx = (wave & 1u) * 8u, ly = (wave >> 1) * 8u;
-    if (quarter < 4u) { // lanes 0..15 walk the 4x4 quarter, the others have nothing to do
-        lx += (quarter & 1u) * 4u + (lane & 3u);
-        ly += (quarter >> 1) * 4u + ((lane >> 2) & 3u);
-    } else {
-        lx += lane & 7u;
-        ly += lane >> 3;
-    }
+    uint32_t lx, ly;
+    lanePixel(wave, quarter, lane, lx, ly);
     const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
     const bool active = (px < p.width) & (py < p.height) & ((quarter == 4u) | (lane < 16u));
 
@@ -149,6 +157,10 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
         pDv[4] = stack.dvL; pDv[5] = stack.dvLLanes; pDv[6] = stack.dvLRuns; pDv[7] = stack.dvLDistinct;
 #endif
         const uint32_t packed = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
+        // where the pixel goes: recomputed from a fresh lane index, so that nothing of it is held (it was spilled) during the traversal
+        uint32_t lx, ly;
+        lanePixel(wave, quarter, __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)), lx, ly);
+        const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
         const size_t pix = static_cast<size_t>(py) * p.width + px;
         if (p.staging) outRgba8[static_cast<size_t>((tile_y * p.tiles_x + tile_x) / p.n_ranks) * (kTile * kTile) + ly * kTile + lx] = packed;
         else outRgba8[pix] = packed;
