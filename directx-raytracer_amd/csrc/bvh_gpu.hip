@@ -13,7 +13,7 @@
 #include "bvh_wide.h"
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include "gpu_sort.hip.h"
 
 #include <algorithm>
 #include <chrono>
@@ -50,13 +50,18 @@ __global__ void initBoundsKernel(int* bounds)
     else if (threadIdx.x < 6) bounds[threadIdx.x] = INT_MIN; // max
 }
 
-// centroid bounds: wave reduction, one atomic pair per wavefront and axis
+// centroid bounds: a fixed grid strides over the centroids, wave reduction, one atomic pair per wavefront and axis
+// (one wavefront per 64 centroids meant 94 k atomics on the same six words at 1M triangles: 1.1 ms, most of it queueing)
+constexpr uint32_t kBoundsBlocks = 256;
 __global__ __launch_bounds__(256) void boundsKernel(const float* __restrict__ cent, uint32_t n, int* bounds)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     int mn[3] = { INT_MAX, INT_MAX, INT_MAX }, mx[3] = { INT_MIN, INT_MIN, INT_MIN };
-    if (i < n)
-        for (int a = 0; a < 3; a++) mn[a] = mx[a] = orderedInt(cent[3 * static_cast<size_t>(i) + a]);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += kBoundsBlocks * 256u)
+        for (int a = 0; a < 3; a++) {
+            const int v = orderedInt(cent[3 * static_cast<size_t>(i) + a]);
+            mn[a] = min(mn[a], v);
+            mx[a] = max(mx[a], v);
+        }
     for (int off = 32; off > 0; off >>= 1)
         for (int a = 0; a < 3; a++) {
             mn[a] = min(mn[a], __shfl_xor(mn[a], off, 64));
@@ -138,21 +143,29 @@ __global__ __launch_bounds__(256) void hierarchyKernel(const unsigned long long*
 
 struct Box6 { float mn[3], mx[3]; };
 
-// bottom-up exact boxes: the second thread to arrive at a node unions its children and moves on.  Workgroups on
-// different XCDs hand boxes to each other through memory, so every hop is fenced at agent scope on both sides
-// (MI355X: per-XCD L2s are not coherent; cdna_hip_programming.md Guideline 16).
+// bottom-up exact boxes: the second thread to arrive at a node unions its children and moves on.  A node whose triangle
+// range lies inside the 256 leaves of one workgroup is only ever touched by that workgroup: arrival counter and fences at
+// workgroup scope, which cost nothing.  A node spanning workgroups hands boxes between XCDs through memory, so those hops
+// are fenced at agent scope on both sides (MI355X: per-XCD L2s are not coherent; cdna_hip_programming.md Guideline 16) --
+// an agent-scope fence per hop for EVERY node was 6.4 of the build's 8.9 ms of kernel time at 1M triangles.
 __global__ __launch_bounds__(256) void fitKernel(const KNode* __restrict__ K, const Box6* __restrict__ pbox, const unsigned long long* __restrict__ keys,
                                                  uint32_t n, const int* __restrict__ parentOfInternal, const int* __restrict__ parentOfLeaf,
                                                  Box6* nodeBox, unsigned int* flags)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= n) return;
+    const uint32_t blockLo = blockIdx.x * 256u, blockHi = blockLo + 255u;
     int p = parentOfLeaf[i];
     while (p >= 0) {
-        __threadfence(); // release what this thread wrote below (if anything) before announcing arrival
-        if (atomicAdd(&flags[p], 1u) == 0u) return; // first arrival: the sibling subtree is not finished yet
-        __threadfence(); // acquire the sibling's boxes
         const KNode k = K[p];
+        unsigned int earlier;
+        if ((k.lo >= blockLo) & (k.hi <= blockHi)) {
+            // release what this thread wrote below, announce arrival, acquire the sibling's boxes: all inside the workgroup
+            earlier = __hip_atomic_fetch_add(&flags[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else {
+            earlier = __hip_atomic_fetch_add(&flags[p], 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (earlier == 0u) return; // first arrival: the sibling subtree is not finished yet
         Box6 b;
         for (int c = 0; c < 2; c++) {
             const int ref = c == 0 ? k.left : k.right;
@@ -169,7 +182,12 @@ __global__ __launch_bounds__(256) void fitKernel(const KNode* __restrict__ K, co
                     b.mx[a] = b.mx[a] > cb.mx[a] ? b.mx[a] : cb.mx[a];
                 }
         }
-        nodeBox[p] = b;
+        // write-through stores: an agent-scope release writes this XCD's dirty L2 lines back, and it is far cheaper when
+        // the 24 MB of boxes this kernel produces are not sitting there dirty
+        for (int a = 0; a < 3; a++) {
+            __hip_atomic_store(&nodeBox[p].mn[a], b.mn[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&nodeBox[p].mx[a], b.mx[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         p = parentOfInternal[p];
     }
 }
@@ -541,10 +559,8 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
     DevBuf dKept(sizeof(uint32_t) * nInternal), dRank(sizeof(uint32_t) * nInternal);
     // the records the kernels will traverse (+64 bytes of slack for speculative wide loads of the last record)
     DevBuf dTris(sizeof(crt_bvh_tri) * n + 64), dShade(sizeof(crt_bvh_shade) * n + 64), dUvs(anyUvs ? sizeof(crt_bvh_uv) * n + 64 : 0);
-    size_t sortBytes = 0, scanBytes = 0;
-    GPU_TRY(hipcub::DeviceRadixSort::SortKeys(nullptr, sortBytes, dKeysIn.as<unsigned long long>(), dKeys.as<unsigned long long>(), static_cast<int>(n), 0, 62, stream));
-    GPU_TRY(hipcub::DeviceScan::ExclusiveSum(nullptr, scanBytes, dKept.as<uint32_t>(), dRank.as<uint32_t>(), static_cast<int>(nInternal), stream));
-    DevBuf dTemp(sortBytes > scanBytes ? sortBytes : scanBytes);
+    // scratch of the sort (digit counts per tile) and of the scan (tile sums); both written by this file's own kernels (gpu_sort.hip.h)
+    DevBuf dSortCounts(sizeof(uint32_t) * gpusort::sortScratchWords(n)), dScanSums(gpusort::scanScratchBytes(nInternal));
 
     GPU_TRY(hipMemcpyAsync(dTable.p, table.data(), sizeof(MeshEntry) * table.size(), hipMemcpyHostToDevice, stream));
     GPU_TRY(hipMemcpyAsync(dXyz.p, hXyz.data(), sizeof(float) * hXyz.size(), hipMemcpyHostToDevice, stream));
@@ -563,15 +579,18 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
     hipLaunchKernelGGL(triBoxKernel, grdN, blk, 0, stream, dTable.as<MeshEntry>(), n_meshes, dXyz.as<float>(), dIdx.as<uint32_t>(), n, dBox.as<Box6>(),
                        dCent.as<float>(), dBad.as<int>());
     hipLaunchKernelGGL(initBoundsKernel, dim3(1), dim3(64), 0, stream, dBounds.as<int>());
-    hipLaunchKernelGGL(boundsKernel, grdN, blk, 0, stream, dCent.as<float>(), n, dBounds.as<int>());
-    hipLaunchKernelGGL(mortonKernel, grdN, blk, 0, stream, dCent.as<float>(), n, dBounds.as<int>(), dKeysIn.as<unsigned long long>());
-    GPU_TRY(hipcub::DeviceRadixSort::SortKeys(dTemp.p, sortBytes, dKeysIn.as<unsigned long long>(), dKeys.as<unsigned long long>(), static_cast<int>(n), 0, 62, stream));
+    hipLaunchKernelGGL(boundsKernel, dim3(kBoundsBlocks), blk, 0, stream, dCent.as<float>(), n, dBounds.as<int>());
+    // keys = Morton code << 32 | ordinal, written in ordinal order: a stable sort on the four bytes of the high dword orders the full keys;
+    // four passes ping-pong dKeys -> dKeysIn -> ... and end in dKeys
+    hipLaunchKernelGGL(mortonKernel, grdN, blk, 0, stream, dCent.as<float>(), n, dBounds.as<int>(), dKeys.as<unsigned long long>());
+    if (gpusort::sortKeysHigh(dKeys.as<unsigned long long>(), dKeysIn.as<unsigned long long>(), n, 4, dSortCounts.as<uint32_t>(), stream) != dKeys.as<unsigned long long>())
+        throw std::logic_error("sorted keys expected in the first buffer");
     hipLaunchKernelGGL(hierarchyKernel, grdI, blk, 0, stream, dKeys.as<unsigned long long>(), n, dK.as<KNode>(), dParI.as<int>(), dParL.as<int>());
     GPU_TRY(hipMemsetAsync(dFlags.p, 0, sizeof(unsigned int) * nInternal, stream));
     hipLaunchKernelGGL(fitKernel, grdN, blk, 0, stream, dK.as<KNode>(), dBox.as<Box6>(), dKeys.as<unsigned long long>(), n, dParI.as<int>(),
                        dParL.as<int>(), dNodeBox.as<Box6>(), dFlags.as<unsigned int>());
     hipLaunchKernelGGL(keptKernel, grdI, blk, 0, stream, dK.as<KNode>(), nInternal, dKept.as<uint32_t>());
-    GPU_TRY(hipcub::DeviceScan::ExclusiveSum(dTemp.p, scanBytes, dKept.as<uint32_t>(), dRank.as<uint32_t>(), static_cast<int>(nInternal), stream));
+    gpusort::exclusiveSum(dKept.as<uint32_t>(), dRank.as<uint32_t>(), nInternal, dScanSums.as<uint32_t>(), stream);
     uint32_t lastKept = 0, lastRank = 0;
     int bad = 0;
     GPU_TRY(hipMemcpyAsync(&lastKept, dKept.as<uint32_t>() + (nInternal - 1), 4, hipMemcpyDeviceToHost, stream));
