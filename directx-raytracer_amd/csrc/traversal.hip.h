@@ -24,7 +24,7 @@ constexpr float kShadowBias = 1e-3f;
 constexpr float kFourPi = 12.566370614359172f;
 constexpr int kDone = INT_MIN;    // traversal finished (not a valid leaf reference)
 constexpr int kBlock = 256;
-constexpr uint32_t kBoostAfter = 300;
+constexpr uint32_t kBoostAfter = 300; // traversal-loop iterations after which a wavefront raises its issue priority
 #ifndef NODE_STEPS
 #define NODE_STEPS 2
 #endif
@@ -36,8 +36,8 @@ constexpr uint32_t kBoostAfter = 300;
 #ifndef CRT_DIAG
 #define CRT_DIAG CRT_PROF
 #endif
-// Register budget: the primary/shadow-ray variant is asked for 7 wavefronts per SIMD (<= 72 VGPRs; one register spilled
-// outside the loops).  With the 64-byte quantised nodes a node in flight is 16 registers instead of 28, and with the LDS
+// Register budget: the primary/shadow-ray variant is asked for 7 wavefronts per SIMD (<= 72 VGPRs; nothing spilled in the
+// headline variant since the pixel position is recomputed after the traversal, render_kernels.hip).  With the 64-byte quantised nodes a node in flight is 16 registers instead of 28, and with the LDS
 // stack at 16 entries (4 KB per wavefront) the CU holds those 28 wavefronts: 0.295 ms against 0.306 at 6 per SIMD;
 // 8 per SIMD (64 VGPRs) spills inside the loops (0.37).  The path-tracing variant keeps the compiler's choice.
 #ifndef CRT_WAVES_PER_EU
@@ -61,9 +61,11 @@ constexpr uint32_t kBoostAfter = 300;
 #ifndef EARLY_FETCH
 #define EARLY_FETCH 1
 #endif
+// the next node's record is requested before the current step's pushes (nodeStepClosestAt)
+// (EARLY_FETCH above); one copy of the traversal loops per direction octant for packets whose rays agree on it
 #ifndef OCTANT_SPECIALISE
 #define OCTANT_SPECIALISE 1
-#endif // traversal-loop iterations after which a wavefront raises its issue priority
+#endif
 constexpr uint32_t kGroupMax = 16; // grid padding unit: tiles per XCD group never exceed this
 
 struct F3 { float x, y, z; };
