@@ -719,7 +719,15 @@ def test_gpu_bvh_build_matches_its_spec_and_renders_identically(pkg, oracle, sce
     small = [{"meshes": [{"vertices": np.concatenate([tri + f([1.5 * i, 0, 0]) for i in range(n)]),
                           "triangles": np.arange(3 * n, dtype=np.uint32).reshape(-1, 3)}], "lights": [], "materials": [],
               "camera": {"position": f([2, 0.3, 0]), "matrix": scenes.IDENTITY}} for n in (1, 2, 4, 5, 9)]
-    cases = [(s, 64, 64, (3,)) for s in small] + [
+    # the radix sort's corners: 5 000 coincident triangles (every Morton code equal: the order is the input order, i.e. the sort
+    # must be stable) and 6 151 triangles in two clumps (three 2 048-key tiles, the last one ragged; two digits only)
+    rng = np.random.default_rng(5)
+    same = {"meshes": [{"vertices": np.tile(tri, (5000, 1)), "triangles": np.arange(15000, dtype=np.uint32).reshape(-1, 3)}], "lights": [],
+            "materials": [], "camera": {"position": f([0.3, 0.3, 0]), "matrix": scenes.IDENTITY}}
+    clump = np.concatenate([tri + (f([0, 0, 0]) if i % 3 else f([40, 0, 0])) + f(rng.uniform(0, 1e-3, 3)) for i in range(6151)])
+    clumps = {"meshes": [{"vertices": clump.astype(np.float32), "triangles": np.arange(3 * 6151, dtype=np.uint32).reshape(-1, 3)}], "lights": [],
+              "materials": [], "camera": {"position": f([0.3, 0.3, 0]), "matrix": scenes.IDENTITY}}
+    cases = [(s, 64, 64, (3,)) for s in small] + [(same, 48, 48, (3,)), (clumps, 48, 48, (3,))] + [
         (scenes.cornell_box(), 256, 256, (3, 100, 200)),
         (_with_normals(scenes, dragon), 640, 360, (0, 100, 200)),
         (scenes.displaced_sphere(), 640, 360, (100,)),
