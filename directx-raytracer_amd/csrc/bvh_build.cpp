@@ -8,6 +8,7 @@
 #include "mem_util.h"
 #include "bvh_build.h"
 #include "bvh_wide.h"
+#include "bvh_pack.h"
 
 #include <atomic>
 #include <cmath>
@@ -374,7 +375,7 @@ void reorderUvs(const std::vector<crt_bvh_uv>& inUv, Bvh& bvh)
     for (size_t i = 0; i < bvh.tris.size(); i++) bvh.uvs[i] = inUv[bvh.tris[i].gid]; // gid = input ordinal
 }
 
-void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
+void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, int width)
 {
     const bool timing = std::getenv("CRT_BUILD_TIMING") != nullptr; // phase breakdown on stderr
     auto tlast = std::chrono::steady_clock::now();
@@ -402,6 +403,10 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
     out.devTris = out.devShade = out.devUvs = nullptr;
     out.devNodes = out.devNodes4 = out.devNodes4q = nullptr;
     out.nNodes = out.nNodes4 = 0;
+    out.width = static_cast<uint32_t>(width);
+    out.packed.clear();
+    out.packedGranules = out.nWide = out.depthWide = 0;
+    out.devPacked = nullptr;
     if (n == 0) return;
 
     std::vector<Box> primBox(n);
@@ -473,11 +478,97 @@ void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out)
     }
     lap("reorder records");
     out.nTris = static_cast<uint32_t>(out.tris.size());
-    collapseBvh4(out);
-    lap("collapse");
     std::vector<crt_bvh_uv> inUv;
     flattenUvs(meshes, n_meshes, inUv);
-    reorderUvs(inUv, out);
+    if (width == 0) {
+        collapseBvh4(out);
+        lap("collapse");
+        reorderUvs(inUv, out);
+    } else {
+        packBvh(out, width);
+        lap("collapse + pack");
+        out.nNodes = static_cast<uint32_t>(out.nodes.size());
+        out.shade = inShade; // the packed tree's triangle records carry their gid: shading records and uvs stay in input order
+        out.uvs = inUv;
+    }
+}
+
+namespace {
+// Binary -> W-wide collapse (the rule of bvh_wide.h wideSlotsT, DFS pre-order) followed by the packing of bvh_pack.h: child
+// blocks in wide-node order behind the root's record; every block holds its node's children in slot order.
+template <int W>
+void packBvhT(Bvh& bvh)
+{
+    typedef PackFmt<W> F;
+    std::vector<WideNodeT<W>> wide;
+    wide.reserve(bvh.nodes.size() / (W / 2) + 1);
+    bvh.depthWide = 0;
+    struct Work { int32_t binary; int32_t parent; int slot; uint32_t depth; };
+    std::vector<Work> work;
+    work.push_back({ 0, -1, 0, 1 });
+    while (!work.empty()) {
+        const Work w = work.back();
+        work.pop_back();
+        WideSlot sl[W];
+        const int n = wideSlotsT<W>(bvh.nodes.data(), w.binary, 0u, sl, nullptr);
+        const int32_t me = static_cast<int32_t>(wide.size());
+        wide.emplace_back();
+        fillWideT<W>(sl, n, wide.back());
+        if (w.parent >= 0) wide[w.parent].ref[w.slot] = me;
+        if (w.depth > bvh.depthWide) bvh.depthWide = w.depth;
+        for (int i = n - 1; i >= 0; i--)
+            if (sl[i].ref >= 0) work.push_back({ sl[i].ref, me, i, w.depth + 1 });
+    }
+    const size_t n = wide.size();
+    // addresses: the root's record at 0, then the child blocks in node order; a node's own record lies in its parent's block
+    std::vector<uint32_t> addr(n), base(n);
+    uint64_t next = F::kNodeGranules;
+    for (size_t i = 0; i < n; i++) {
+        base[i] = static_cast<uint32_t>(next);
+        next += blockGranules<W>(wide[i]);
+        if (next >= (1ull << 29)) throw std::runtime_error("scene too large for the packed tree's 29-bit addresses");
+    }
+    addr[0] = 0;
+    for (size_t i = 0; i < n; i++) { // parents precede their children in pre-order
+        uint32_t off = 0;
+        for (int k = 0; k < W; k++) {
+            const int32_t ref = wide[i].ref[k];
+            if (ref >= 0) addr[ref] = base[i] + off;
+            else if ((static_cast<uint32_t>(~ref) & 7u) > kPackLeafMax) throw std::runtime_error("leaf too large for the packed tree");
+            off += childGranules<W>(ref);
+        }
+    }
+    const size_t dwordsPerGranule = F::kGranuleBytes / 4;
+    bvh.packed.assign(static_cast<size_t>(next) * dwordsPerGranule, 0u);
+    bvh.packedGranules = static_cast<uint32_t>(next);
+    bvh.nWide = static_cast<uint32_t>(n);
+    const int64_t nn = static_cast<int64_t>(n);
+#pragma omp parallel for schedule(static) if (nn > 65536)
+    for (int64_t i = 0; i < nn; i++) {
+        const WideNodeT<W>& N = wide[static_cast<size_t>(i)];
+        packNode<W>(N, base[i], &bvh.packed[static_cast<size_t>(addr[i]) * dwordsPerGranule]);
+        uint32_t off = 0;
+        for (int k = 0; k < W; k++) {
+            const int32_t ref = N.ref[k];
+            if (ref < 0) {
+                const uint32_t code = static_cast<uint32_t>(~ref), first = code >> 3, cnt = code & 7u;
+                if (cnt) crt::copyBytes(&bvh.packed[static_cast<size_t>(base[i] + off) * dwordsPerGranule], &bvh.tris[first], sizeof(crt_bvh_tri) * cnt);
+            }
+            off += childGranules<W>(ref);
+        }
+    }
+}
+} // namespace
+
+void packBvh(Bvh& bvh, int width)
+{
+    bvh.packed.clear();
+    bvh.packedGranules = bvh.nWide = bvh.depthWide = 0;
+    bvh.width = static_cast<uint32_t>(width);
+    if (bvh.nodes.empty()) return;
+    if (width == 4) packBvhT<4>(bvh);
+    else if (width == 8) packBvhT<8>(bvh);
+    else throw std::runtime_error("packed tree width must be 4 or 8");
 }
 
 // Binary -> 4-wide collapse.  A wide node takes the two children of a binary node and, while it has fewer than four

@@ -38,10 +38,18 @@ struct Bvh {
     void* devNodes4 = nullptr;
     void* devNodes4q = nullptr;
     uint32_t nNodes = 0, nNodes4 = 0;
+    // packed wide tree (bvh_pack.h; width 4 or 8, 0 = none: the legacy 64-byte nodes above are what is traversed): node and
+    // triangle records in ONE buffer; shade / uvs are then indexed by gid (input order), not by leaf position
+    uint32_t width = 0;
+    std::vector<uint32_t> packed;      // dwords
+    uint32_t packedGranules = 0;       // length of the buffer in granules (48 B for width 4, 16 B for width 8)
+    uint32_t nWide = 0, depthWide = 0; // wide nodes, levels
+    void* devPacked = nullptr;
 };
 
 // meshes in InstanceID order; triangle gid = running ordinal over meshes. Throws std::runtime_error on bad input.
-void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out);
+// width: 0 = legacy 4-wide tree with 64-byte nodes and separate triangle array; 4 / 8 = packed wide tree (bvh_pack.h)
+void buildBvh(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, int width = 0);
 // shared first step of both builders (see bvh_build.cpp)
 void flattenMeshes(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<crt_bvh_tri>& inTri, std::vector<crt_bvh_shade>& inShade,
                    std::vector<float>& boxCent);
@@ -52,6 +60,8 @@ void flattenUvs(const crt_mesh_view* meshes, uint32_t n_meshes, std::vector<crt_
 void reorderUvs(const std::vector<crt_bvh_uv>& inUv, Bvh& bvh);
 // binary -> wide collapse (DESIGN.md "BVH4"); called by both builders
 void collapseBvh4(Bvh& bvh);
+// binary -> W-wide collapse + packing into the single buffer; needs bvh.nodes and the leaf-ordered bvh.tris
+void packBvh(Bvh& bvh, int width);
 // (the collapse and quantisation rules themselves: bvh_wide.h, shared with the GPU builder)
 
 } // namespace crt

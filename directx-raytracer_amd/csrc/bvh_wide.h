@@ -38,15 +38,16 @@ CRT_HD inline void binaryChildren(const crt_bvh_node& N, uint32_t depthOfN, Wide
     l.depth = r.depth = depthOfN + 1u;
 }
 
-// The slots of the wide node rooted at binary node `b`: its two children, then, while fewer than four, the inner slot of
+// The slots of the W-wide node rooted at binary node `b`: its two children, then, while fewer than W, the inner slot of
 // largest half-area (first on ties) replaced in place by its two children (left keeps the position, right goes right after
 // it).  Returns the slot count; *deepest = the largest depth + 1 over b and the binary nodes absorbed.
-CRT_HD inline int wideSlots(const crt_bvh_node* nodes, int32_t b, uint32_t depthOfB, WideSlot sl[4], uint32_t* deepest)
+template <int W>
+CRT_HD inline int wideSlotsT(const crt_bvh_node* nodes, int32_t b, uint32_t depthOfB, WideSlot* sl /* [W] */, uint32_t* deepest)
 {
     int n = 2;
     binaryChildren(nodes[b], depthOfB, sl[0], sl[1]);
     uint32_t deep = depthOfB + 1u;
-    while (n < 4) {
+    while (n < W) {
         int best = -1;
         float bestArea = -1.0f;
         for (int i = 0; i < n; i++) {
@@ -65,6 +66,10 @@ CRT_HD inline int wideSlots(const crt_bvh_node* nodes, int32_t b, uint32_t depth
     }
     if (deepest) *deepest = deep;
     return n;
+}
+CRT_HD inline int wideSlots(const crt_bvh_node* nodes, int32_t b, uint32_t depthOfB, WideSlot sl[4], uint32_t* deepest)
+{
+    return wideSlotsT<4>(nodes, b, depthOfB, sl, deepest);
 }
 
 // the wide node of n slots, inner refs still binary indices; unused slots: an inverted box and CRT_BVH_EMPTY (quantised: a point)

@@ -64,6 +64,7 @@ struct crt_ctx {
     uint32_t nLights = 0, nMats = 0;
     bool haveScene = false;
     bool gpuBuild = false;      // option "gpu_build": LBVH on the device instead of the host SAH builder
+    uint32_t bvhWidth = 0;      // option "bvh_width": 0 = legacy 64-byte 4-wide nodes, 4 / 8 = packed wide tree (bvh_pack.h), at the next upload
     double buildMs = 0.0;       // wall time of the last crt_upload_scene (build + upload)
     double buildDeviceMs = 0.0; // of which GPU kernels (gpu_build only)
     uint32_t sceneSerial = 0;
@@ -190,7 +191,7 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
 {
     std::memset(&p, 0, sizeof(p));
     p.nodes = c->dNodes;
-    p.tris = c->dTris;
+    p.tris = c->bvh.width ? c->dNodes : c->dTris;
     p.shade = c->dShade;
     p.lights = c->dLights;
     p.mats = c->dMats;
@@ -198,7 +199,8 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.textures = c->dTextures;
     p.texels = static_cast<const unsigned char*>(c->dTexels);
     p.n_textures = c->nTextures;
-    p.n_nodes = c->bvh.nNodes4;
+    p.layout = c->bvh.width;
+    p.n_nodes = c->bvh.width ? c->bvh.nWide : c->bvh.nNodes4;
     p.n_tris = c->bvh.nTris;
     p.n_lights = c->nLights;
     p.n_mats = c->nMats;
@@ -257,7 +259,7 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
     const uint32_t slot = c->frameSerial++ % crt_ctx::kRing;
     {
         // deepest stack a ray can build: three pending siblings per wide level; what does not fit the LDS part spills
-        const uint32_t deepest = 3u * c->bvh.depth4 + 1u;
+        const uint32_t deepest = c->bvh.width ? (c->bvh.width - 1u) * c->bvh.depthWide + 1u : 3u * c->bvh.depth4 + 1u;
         p.spill_stride = deepest > p.stack_entries ? deepest - p.stack_entries : 1u;
         const size_t need = static_cast<size_t>(crt::renderUnitCount(p)) * p.n_batch * 64u * p.spill_stride * sizeof(int);
         if (c->spillBytes[slot] < need) {
@@ -541,7 +543,7 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
             HIP_TRY(c, hipSetDevice(c->device));
             crt::buildBvhGpu(meshes, n_meshes, built, c->stream, &deviceMs);
         } else {
-            crt::buildBvh(meshes, n_meshes, built);
+            crt::buildBvh(meshes, n_meshes, built, static_cast<int>(c->bvhWidth));
         }
     } catch (const std::bad_alloc&) {
         return fail(c, CRT_ENOMEM, "out of host memory while building the BVH");
@@ -577,15 +579,21 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     const size_t nb = sizeof(crt_bvh_node4q) * c->bvh.nodes4q.size(); // the quantised wide tree is what the kernels traverse
     const size_t tb = sizeof(crt_bvh_tri) * c->bvh.nTris;
     const size_t sb = sizeof(crt_bvh_shade) * c->bvh.nTris;
+    const bool packed = c->bvh.width != 0;
     // +64 bytes of slack so that a speculative wide load of the last record stays inside the allocation
+    if (packed && !c->dNodes) { // nodes and triangles in one buffer: dTris stays empty, the kernels get dNodes for both
+        const size_t pb = c->bvh.packed.size() * sizeof(uint32_t);
+        HIP_TRY(c, hipMalloc(&c->dNodes, pb + 128));
+        if (pb) HIP_TRY(c, hipMemcpy(c->dNodes, c->bvh.packed.data(), pb, hipMemcpyHostToDevice));
+    }
     if (!c->dNodes) { // (a tree collapsed on the device is already there)
         HIP_TRY(c, hipMalloc(&c->dNodes, nb + 128));
         if (nb) HIP_TRY(c, hipMemcpy(c->dNodes, c->bvh.nodes4q.data(), nb, hipMemcpyHostToDevice));
     }
     if (!recordsOnDevice) {
-        HIP_TRY(c, hipMalloc(&c->dTris, tb + 64));
+        if (!packed) HIP_TRY(c, hipMalloc(&c->dTris, tb + 64));
         HIP_TRY(c, hipMalloc(&c->dShade, sb + 64));
-        if (tb) HIP_TRY(c, hipMemcpy(c->dTris, c->bvh.tris.data(), tb, hipMemcpyHostToDevice));
+        if (tb && !packed) HIP_TRY(c, hipMemcpy(c->dTris, c->bvh.tris.data(), tb, hipMemcpyHostToDevice));
         if (sb) HIP_TRY(c, hipMemcpy(c->dShade, c->bvh.shade.data(), sb, hipMemcpyHostToDevice));
         if (!c->bvh.uvs.empty()) {
             const size_t ub = sizeof(crt_bvh_uv) * c->bvh.uvs.size();
@@ -695,6 +703,16 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
         c->gpuBuild = value != 0;
         return CRT_OK;
     }
+#if defined(CRT_PACKED_LAYOUTS) && CRT_PACKED_LAYOUTS
+    // round-3 experiment (tools/variant_build.sh packed "-DCRT_PACKED_LAYOUTS=1", tools/width_ab.py): 0 = the product's 64-byte
+    // 4-wide nodes, 4 / 8 = packed wide tree (bvh_pack.h), taken at the next crt_upload_scene; host build only
+    if (std::strcmp(name, "bvh_width") == 0 && (value == 0 || value == 4 || value == 8)) {
+        c->bvhWidth = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+#else
+    if (std::strcmp(name, "bvh_width") == 0 && value == 0) return CRT_OK;
+#endif
     if (std::strcmp(name, "spp") == 0 && value >= 1 && value <= 65536) {
         c->pathSpp = static_cast<uint32_t>(value);
         c->viewSerial++;

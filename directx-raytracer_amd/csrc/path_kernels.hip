@@ -46,23 +46,22 @@ __device__ __forceinline__ uint32_t lanePrefix(unsigned long long m)
 #ifndef CRT_REFILL_MIN
 #define CRT_REFILL_MIN 16
 #endif
-template <bool COUNT>
+template <bool COUNT, class L>
 __device__ __forceinline__ void streamClosest(const float4* __restrict__ nodes, const float4* __restrict__ tris, uint32_t n_nodes,
                                               const PathScratch& q, uint32_t nTrace, uint32_t& nShade, F3 miss, Stack& stack, int innerMin,
                                               uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntClosest)
 {
-    constexpr int BLOCK = 64;
     Ray r = makeRay(f3(0.0f, 0.0f, 0.0f), f3(0.0f, 0.0f, 1.0f));
     Hit h;
     h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
     float tcull = kTMax * kCullPad;
-    int cur = kDone;
+    int cur = L::kDone;
     bool have = false;   // this lane holds a ray (being traced, or finished and not yet retired)
     uint32_t my = 0;     // its index in the trace queue
     uint32_t next = 0;   // wave-uniform: first queue entry not yet handed to a lane
     const unsigned long long all = __ballot(true);
     for (;;) {
-        const bool idle = cur == kDone;
+        const bool idle = cur == L::kDone;
         const unsigned long long idleMask = __ballot(idle);
         if (idleMask == all || (next < nTrace && static_cast<uint32_t>(__popcll(idleMask)) >= static_cast<uint32_t>(CRT_REFILL_MIN))) {
             // retire the finished rays ...
@@ -93,14 +92,14 @@ __device__ __forceinline__ void streamClosest(const float4* __restrict__ nodes, 
                     h.t = kTMax; h.u = 0.0f; h.v = 0.0f; h.tri = 0; h.gid = 0;
                     tcull = kTMax * kCullPad;
                     stack.sp = 0;
-                    cur = n_nodes ? 0 : kDone;
+                    cur = n_nodes ? L::kRoot : L::kDone;
                     if (COUNT) cntClosest++;
                 }
             }
             next += static_cast<uint32_t>(__popcll(idleMask));
             if (__ballot(have) == 0ull) break; // queue empty and every ray retired
         }
-        closestIteration<COUNT, BLOCK, 8>(nodes, tris, r, 0.0f, tcull, stack, innerMin, h, cur, iters, cntNodes, cntTris);
+        closestIteration<COUNT, L, 8>(nodes, tris, r, 0.0f, tcull, stack, innerMin, h, cur, iters, cntNodes, cntTris);
     }
 }
 
@@ -109,17 +108,16 @@ __device__ __forceinline__ void streamClosest(const float4* __restrict__ nodes, 
 // positive cosine, in light order: one any-hit shadow ray, its contribution added when unoccluded (oracle: direct_light) ->
 // retire (radiance update, next direction drawn, appended to the trace queue or written out as finished).  Shadow rays end at
 // their first hit, so their traversals differ even more in length than the bounce rays': refilling keeps the wavefront full.
-template <bool COUNT>
+template <bool COUNT, class L>
 __device__ __forceinline__ void streamShade(const RenderParams& p, const float4* __restrict__ nodes, const float4* __restrict__ tris,
                                             const PathScratch& q, uint32_t nShade, uint32_t& nTrace, Stack& stack, int innerMin,
                                             uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
 {
-    constexpr int BLOCK = 64;
     const LightRec* lights = reinterpret_cast<const LightRec*>(p.lights);
     Ray sr = makeRay(f3(0.0f, 0.0f, 0.0f), f3(0.0f, 0.0f, 1.0f)); // the shadow ray in flight
     float dist = 0.0f, tcull = 0.0f, kcur = 0.0f;                  // its length, cull bound, and the light's weight if it arrives
     bool occluded = false;
-    int cur = kDone;
+    int cur = L::kDone;
     bool have = false, diffuse = false, tracing = false, alive = false;
     float thrMul = 0.0f;  // 1: throughput *= albedo when the path goes on; -1: CONSTANT (radiance += throughput * albedo)
     uint32_t my = 0, li = 0;
@@ -128,7 +126,7 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
     uint32_t next = 0;
     const unsigned long long all = __ballot(true);
     for (;;) {
-        const bool idle = cur == kDone;
+        const bool idle = cur == L::kDone;
         const unsigned long long idleMask = __ballot(idle);
         if (idleMask == all || (next < nShade && static_cast<uint32_t>(__popcll(idleMask)) >= static_cast<uint32_t>(CRT_REFILL_MIN))) {
             // 1. a shadow ray has come back: its light counts unless something is in the way
@@ -139,7 +137,7 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
             }
             // 2. retire: the entries whose lights are all done (or that never had any to ask)
             const bool retire = idle & have & !(diffuse & (li < p.n_lights));
-            F3 thr = f3(0.f, 0.f, 0.f), L = f3(0.f, 0.f, 0.f), nd = f3(0.f, 0.f, 0.f);
+            F3 thr = f3(0.f, 0.f, 0.f), Lr = f3(0.f, 0.f, 0.f), nd = f3(0.f, 0.f, 0.f);
             uint32_t rng = 0, idb = 0;
             bool goesOn = false;
             if (retire) {
@@ -147,12 +145,12 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
                 idb = __float_as_uint(q.shade[q.B + my].w);
                 const float4 a2 = q.thr[idb & 0xFFFFu], a3 = q.done[idb & 0xFFFFu];
                 thr = f3(a2.x, a2.y, a2.z);
-                L = f3(a3.x, a3.y, a3.z);
+                Lr = f3(a3.x, a3.y, a3.z);
                 goesOn = alive;
                 nd = aux;
-                if (thrMul < 0.0f) L = f3(fmaf(thr.x, albedo.x, L.x), fmaf(thr.y, albedo.y, L.y), fmaf(thr.z, albedo.z, L.z));
+                if (thrMul < 0.0f) Lr = f3(fmaf(thr.x, albedo.x, Lr.x), fmaf(thr.y, albedo.y, Lr.y), fmaf(thr.z, albedo.z, Lr.z));
                 if (diffuse) {
-                    L = f3(fmaf(thr.x, aux.x, L.x), fmaf(thr.y, aux.y, L.y), fmaf(thr.z, aux.z, L.z));
+                    Lr = f3(fmaf(thr.x, aux.x, Lr.x), fmaf(thr.y, aux.y, Lr.y), fmaf(thr.z, aux.z, Lr.z));
                     if ((idb >> 16) != p.max_bounces) {
                         const float u1 = rngNext(rng), u2 = rngNext(rng);
                         const float rr = sqrtf(u1), phi = 6.28318530717958648f * u2;
@@ -173,7 +171,7 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
                     thr = f3(thr.x * albedo.x, thr.y * albedo.y, thr.z * albedo.z);
                     if (goesOn) q.thr[idb & 0xFFFFu] = make_float4(thr.x, thr.y, thr.z, 0.0f);
                 }
-                q.done[idb & 0xFFFFu] = make_float4(L.x, L.y, L.z, 0.0f); // final if the path ends here, else the sum so far
+                q.done[idb & 0xFFFFu] = make_float4(Lr.x, Lr.y, Lr.z, 0.0f); // final if the path ends here, else the sum so far
                 have = false;
             }
             const unsigned long long mOn = __ballot(goesOn);
@@ -196,7 +194,7 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
                 Hit h;
                 const float4 a4 = q.shade[2u * q.B + idx];
                 h.t = a4.x; h.u = a4.y; h.v = a4.z; h.tri = __float_as_uint(a4.w); h.gid = 0;
-                const Surface sf = surfaceAt(p, tris, r, h);
+                const Surface sf = surfaceAt<L>(p, tris, r, h);
                 N = sf.N;
                 albedo = sf.albedo;
                 diffuse = false; alive = false; thrMul = 0.0f; li = 0;
@@ -234,7 +232,7 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
             }
             next += static_cast<uint32_t>(__popcll(mNew));
             // 4. the next light of every diffuse entry that is not waiting for a shadow ray
-            if ((cur == kDone) & have & diffuse & !tracing) {
+            if ((cur == L::kDone) & have & diffuse & !tracing) {
                 while (li < p.n_lights) {
                     const LightRec Lt = lights[li];
                     const F3 Lv = sub3(f3(Lt.x, Lt.y, Lt.z), Po);
@@ -251,7 +249,7 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
                         occluded = false;
                         tracing = true;
                         stack.sp = 0;
-                        cur = p.n_nodes ? 0 : kDone;
+                        cur = p.n_nodes ? L::kRoot : L::kDone;
                         if (COUNT) cntShadow++;
                         break;
                     }
@@ -260,14 +258,14 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
             }
             if (__ballot(have) == 0ull) break;
         }
-        anyIteration<COUNT, BLOCK, 8>(nodes, tris, sr, 0.0f, dist, tcull, stack, innerMin, occluded, cur, iters, cntNodes, cntTris);
+        anyIteration<COUNT, L, 8>(nodes, tris, sr, 0.0f, dist, tcull, stack, innerMin, occluded, cur, iters, cntNodes, cntTris);
     }
 }
 
 #ifndef CRT_PATH_WAVES_PER_EU
 #define CRT_PATH_WAVES_PER_EU 5
 #endif
-template <bool COUNT>
+template <bool COUNT, class L>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAVES_PER_EU, 8))) void pathKernel(const RenderParams p)
 {
     extern __shared__ int s_stack[];
@@ -304,7 +302,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
     stack.spill = p.spill + (static_cast<size_t>(blockIdx.x) * 64u + lane) * p.spill_stride;
     stack.cap = static_cast<int>(p.stack_entries);
     stack.sp = 0;
-    constexpr int BLOCK = 64;
     const int innerMin = static_cast<int>(p.tune_inner_min);
 
     PathScratch q;
@@ -341,7 +338,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
                     const float jx = rngNext(rng), jy = rngNext(rng);
                     r = makeRay(f3(camPos[0], camPos[1], camPos[2]), rayDirJ(camRot, px, py, jx, jy, static_cast<float>(p.width), static_cast<float>(p.height)));
                     if (COUNT) cntClosest++;
-                    traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, innerMin, h, iters, cntNodes, cntTris);
+                    traceClosest<COUNT, L>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, innerMin, h, iters, cntNodes, cntTris);
                     isHit = h.t < kTMax;
                     // radiance so far: a miss ends the path with throughput (1) x miss colour; a hit starts from nothing, throughput 1
                     q.done[id] = isHit ? make_float4(0.0f, 0.0f, 0.0f, 0.0f) : make_float4(fmaf(1.0f, miss.x, 0.0f), fmaf(1.0f, miss.y, 0.0f), fmaf(1.0f, miss.z, 0.0f), 0.0f);
@@ -350,7 +347,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
                         const size_t pix = static_cast<size_t>(py) * p.width + px;
                         uint32_t inst = 0xFFFFFFFFu, prim = 0xFFFFFFFFu;
                         if (isHit) {
-                            const float4* T = tris + 3 * static_cast<size_t>(h.tri);
+                            const float4* T = L::triPtr(tris, h.tri);
                             inst = __float_as_uint(T[0].w);
                             prim = __float_as_uint(T[1].w);
                         }
@@ -372,9 +369,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
         // ---- stages B / C until no path is left
         while (nShade != 0u) {
             uint32_t nTrace = 0;
-            streamShade<COUNT>(p, nodes, tris, q, nShade, nTrace, stack, innerMin, iters, cntNodes, cntTris, cntShadow); // stage B
+            streamShade<COUNT, L>(p, nodes, tris, q, nShade, nTrace, stack, innerMin, iters, cntNodes, cntTris, cntShadow); // stage B
             nShade = 0;
-            streamClosest<COUNT>(nodes, tris, p.n_nodes, q, nTrace, nShade, miss, stack, innerMin, iters, cntNodes, cntTris, cntClosest); // stage C
+            streamClosest<COUNT, L>(nodes, tris, p.n_nodes, q, nTrace, nShade, miss, stack, innerMin, iters, cntNodes, cntTris, cntClosest); // stage C
         }
         // ---- this pass's samples join the running sums in sample order; after the last pass: average, quantise, store
         const bool last = s0 + nS >= p.spp;
@@ -438,8 +435,16 @@ int launchPath(const RenderParams& p, bool counting, ihipStream_t* stream)
     // one wavefront per pixel tile carries all its paths through the pipeline
     const dim3 grid(pathWorkgroupCount(p)), block(64);
     const size_t lds = static_cast<size_t>(p.stack_entries) * 64u * sizeof(int);
-    if (counting) hipLaunchKernelGGL((pathKernel<true>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((pathKernel<false>), grid, block, lds, stream, p);
+#define CRT_LAUNCH(LAY)                                                                                \
+    if (counting) hipLaunchKernelGGL((pathKernel<true, LAY>), grid, block, lds, stream, p);            \
+    else hipLaunchKernelGGL((pathKernel<false, LAY>), grid, block, lds, stream, p);
+#if CRT_PACKED_LAYOUTS
+    if (p.layout == 8u) { CRT_LAUNCH(LayPacked<8>) }
+    else if (p.layout == 4u) { CRT_LAUNCH(LayPacked<4>) }
+    else
+#endif
+    { CRT_LAUNCH(LayLegacy) }
+#undef CRT_LAUNCH
     return static_cast<int>(hipGetLastError());
 }
 

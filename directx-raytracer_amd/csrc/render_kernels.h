@@ -13,8 +13,9 @@ constexpr int kStackEntries = 32;  // upper bound of the per-lane LDS traversal 
 
 struct RenderParams {
     // scene (HBM)
-    const void* nodes;   // crt_bvh_node4q[n_nodes], 64 B (the quantised wide tree)
-    const void* tris;    // crt_bvh_tri[n_tris], 48 B
+    const void* nodes;   // crt_bvh_node4q[n_nodes], 64 B (the quantised wide tree); layout 4 / 8: the packed buffer (bvh_pack.h)
+    const void* tris;    // crt_bvh_tri[n_tris], 48 B; layout 4 / 8: the same packed buffer
+    uint32_t layout;     // 0: legacy 64-byte 4-wide nodes + triangle array; 4 / 8: packed wide tree of that width
     const void* shade;   // crt_bvh_shade[n_tris], 48 B
     const void* lights;  // crt_light[n_lights]
     const void* mats;    // crt_material[n_mats] (28 B)

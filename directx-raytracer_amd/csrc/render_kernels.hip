@@ -33,8 +33,8 @@ __device__ __forceinline__ void lanePixel(uint32_t wave, uint32_t quarter, uint3
     }
 }
 
-template <bool COUNT, bool PHONG>
-__global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const RenderParams p)
+template <bool COUNT, bool PHONG, class L>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L::kWavesPerEu, 8))) void renderKernel(const RenderParams p)
 {
     extern __shared__ int s_stack[]; // stack_entries x 256 dwords, sized at launch from the BVH depth
     unsigned long long t_start = 0;
@@ -128,7 +128,6 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
         stack.cap = static_cast<int>(p.stack_entries);
         stack.sp = 0;
 
-        constexpr int BLOCK = 64;
         F3 col;
         uint32_t inst = 0xFFFFFFFFu, prim = 0xFFFFFFFFu;
         Hit h;
@@ -136,17 +135,17 @@ __global__ __launch_bounds__(64) CRT_OCCUPANCY_ATTR void renderKernel(const Rend
             const F3 o = f3(camPos[0], camPos[1], camPos[2]);
             const Ray r = makeRay(o, rayDir(camRot, px, py, static_cast<float>(p.width), static_cast<float>(p.height)));
             if (COUNT) cntClosest++;
-            traceClosest<COUNT, BLOCK>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, iters, cntNodes, cntTris);
+            traceClosest<COUNT, L>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, iters, cntNodes, cntTris);
             col = f3(p.miss[0], p.miss[1], p.miss[2]); // miss shader (hlsl:72-76)
             if (h.t < kTMax) {
-                const float4* T = tris + 3 * static_cast<size_t>(h.tri);
-                if (p.mode >= 100u) col = shadeLambert<COUNT, BLOCK, PHONG>(p, nodes, tris, r, h, stack, iters, cntNodes, cntTris, cntShadow);
+                const float4* T = L::triPtr(tris, h.tri);
+                if (p.mode >= 100u) col = shadeLambert<COUNT, L, PHONG>(p, nodes, tris, r, h, stack, iters, cntNodes, cntTris, cntShadow);
                 else col = shadeDebug(p.mode, __float_as_uint(T[0].w), __float_as_uint(T[1].w), h.t, h.u, h.v, r.o, r.d);
             }
         }
         const bool hit = h.t < kTMax;
         if (hit) {
-            const float4* T = tris + 3 * static_cast<size_t>(h.tri);
+            const float4* T = L::triPtr(tris, h.tri);
             inst = __float_as_uint(T[0].w);
             prim = __float_as_uint(T[1].w);
         }
@@ -252,10 +251,18 @@ int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream)
     {
         const dim3 grid((n * 4u + (p.unit_order ? 3u * p.split_units : 0u)) * (p.n_batch ? p.n_batch : 1u));
         const bool phong = p.mode >= 100u && p.phong_ks > 0.0f;
-        if (counting && phong) hipLaunchKernelGGL((renderKernel<true, true>), grid, block, lds, stream, p);
-        else if (counting) hipLaunchKernelGGL((renderKernel<true, false>), grid, block, lds, stream, p);
-        else if (phong) hipLaunchKernelGGL((renderKernel<false, true>), grid, block, lds, stream, p);
-        else hipLaunchKernelGGL((renderKernel<false, false>), grid, block, lds, stream, p);
+#define CRT_LAUNCH(LAY)                                                                                                \
+        if (counting && phong) hipLaunchKernelGGL((renderKernel<true, true, LAY>), grid, block, lds, stream, p);       \
+        else if (counting) hipLaunchKernelGGL((renderKernel<true, false, LAY>), grid, block, lds, stream, p);          \
+        else if (phong) hipLaunchKernelGGL((renderKernel<false, true, LAY>), grid, block, lds, stream, p);             \
+        else hipLaunchKernelGGL((renderKernel<false, false, LAY>), grid, block, lds, stream, p);
+#if CRT_PACKED_LAYOUTS
+        if (p.layout == 8u) { CRT_LAUNCH(LayPacked<8>) }
+        else if (p.layout == 4u) { CRT_LAUNCH(LayPacked<4>) }
+        else
+#endif
+        { CRT_LAUNCH(LayLegacy) }
+#undef CRT_LAUNCH
     }
     return static_cast<int>(hipGetLastError());
 }

@@ -108,12 +108,14 @@ struct Surface {
     float ior;
 };
 
+template <class L>
 __device__ __forceinline__ Surface surfaceAt(const RenderParams& p, const float4* tris, const Ray& r, const Hit& h)
 {
     Surface sf;
-    const float4* T = tris + 3 * static_cast<size_t>(h.tri);
+    const float4* T = L::triPtr(tris, h.tri);
     const float4 tb = T[1], tc = T[2];
-    const float* S = reinterpret_cast<const float*>(p.shade) + 12 * static_cast<size_t>(h.tri);
+    const uint32_t rec = L::shadeIndex(h.tri, __float_as_uint(tc.w)); // shading / uv record: leaf order, or input order (packed tree)
+    const float* S = reinterpret_cast<const float*>(p.shade) + 12 * static_cast<size_t>(rec);
     const uint32_t material = __float_as_uint(S[9]);
     sf.P = f3(r.o.x + r.d.x * h.t, r.o.y + r.d.y * h.t, r.o.z + r.d.z * h.t);
     sf.albedo = f3(1.0f, 1.0f, 1.0f);
@@ -134,7 +136,7 @@ __device__ __forceinline__ Surface surfaceAt(const RenderParams& p, const float4
                 tu = 0.0f;
                 tv = 0.0f;
                 if (p.uvs) {
-                    const float* U = reinterpret_cast<const float*>(p.uvs) + 6 * static_cast<size_t>(h.tri);
+                    const float* U = reinterpret_cast<const float*>(p.uvs) + 6 * static_cast<size_t>(rec);
                     const float w = 1.0f - h.u - h.v;
                     tu = fmaf(U[4], h.v, fmaf(U[2], h.u, U[0] * w));
                     tv = fmaf(U[5], h.v, fmaf(U[3], h.u, U[1] * w));
@@ -179,15 +181,15 @@ __device__ __forceinline__ float powUint(float x, uint32_t n)
 
 // direct light at Po: one any-hit shadow ray per light with a positive cosine (oracle: direct_light).  PHONG (mode 100
 // only): plus the specular term ks * I / (4 pi r^2) * max(0, R . view)^n, R = the light direction mirrored about N.
-template <bool COUNT, int BLOCK, bool PHONG>
+template <bool COUNT, class L, bool PHONG>
 __device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* nodes, const float4* tris, F3 Po, F3 N, F3 albedo, F3 view,
                                           Stack& stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
 {
     F3 rgb = f3(0.0f, 0.0f, 0.0f);
     const LightRec* lights = reinterpret_cast<const LightRec*>(p.lights);
     for (uint32_t li = 0; li < p.n_lights; li++) {
-        const LightRec L = lights[li];
-        const F3 Lv = sub3(f3(L.x, L.y, L.z), Po);
+        const LightRec Lt = lights[li];
+        const F3 Lv = sub3(f3(Lt.x, Lt.y, Lt.z), Po);
         const float r2 = dot3(Lv, Lv);
         const float dist = sqrtf(r2);
         const float invr = 1.0f / dist;
@@ -196,9 +198,9 @@ __device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* n
         if (cosv > 0.0f) {
             const Ray sr = makeRay(Po, Ld);
             if (COUNT) cntShadow++;
-            const bool occluded = traceAny<COUNT, BLOCK>(nodes, tris, p.n_nodes, sr, 0.0f, dist, stack, static_cast<int>(p.tune_inner_min), iters, cntNodes, cntTris);
+            const bool occluded = traceAny<COUNT, L>(nodes, tris, p.n_nodes, sr, 0.0f, dist, stack, static_cast<int>(p.tune_inner_min), iters, cntNodes, cntTris);
             if (!occluded) {
-                const float k = (L.intensity / (kFourPi * r2)) * cosv;
+                const float k = (Lt.intensity / (kFourPi * r2)) * cosv;
                 rgb.x = fmaf(albedo.x, k, rgb.x);
                 rgb.y = fmaf(albedo.y, k, rgb.y);
                 rgb.z = fmaf(albedo.z, k, rgb.z);
@@ -206,7 +208,7 @@ __device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* n
                     const float nl2 = 2.0f * dot3(N, Ld);
                     const F3 R = f3(fmaf(nl2, N.x, -Ld.x), fmaf(nl2, N.y, -Ld.y), fmaf(nl2, N.z, -Ld.z));
                     const float rv = fmaxf(0.0f, dot3(R, view));
-                    const float sp = (p.phong_ks * (L.intensity / (kFourPi * r2))) * powUint(rv, p.phong_exp);
+                    const float sp = (p.phong_ks * (Lt.intensity / (kFourPi * r2))) * powUint(rv, p.phong_exp);
                     rgb.x += sp; rgb.y += sp; rgb.z += sp;
                 }
             }
@@ -216,12 +218,12 @@ __device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* n
 }
 
 // mode 100: Lambert (+ optional Phong highlight) + one shadow ray per light, every material treated as diffuse (oracle: shade_lambert)
-template <bool COUNT, int BLOCK, bool PHONG>
+template <bool COUNT, class L, bool PHONG>
 __device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* nodes, const float4* tris, const Ray& r,
                                            const Hit& h, Stack& stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
 {
-    const Surface sf = surfaceAt(p, tris, r, h);
-    return directLight<COUNT, BLOCK, PHONG>(p, nodes, tris, biasPoint(sf.P, sf.N, kShadowBias), sf.N, sf.albedo, f3(-r.d.x, -r.d.y, -r.d.z), stack, iters, cntNodes, cntTris, cntShadow);
+    const Surface sf = surfaceAt<L>(p, tris, r, h);
+    return directLight<COUNT, L, PHONG>(p, nodes, tris, biasPoint(sf.P, sf.N, kShadowBias), sf.N, sf.albedo, f3(-r.d.x, -r.d.y, -r.d.z), stack, iters, cntNodes, cntTris, cntShadow);
 }
 
 // ---- mode 200: path tracing (oracle: trace_path). Counter-based RNG keyed by (pixel, sample, seed).
