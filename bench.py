@@ -2,8 +2,9 @@
 """Headline benchmark (BASELINE.json): Mray/s and ms/frame at 1920x1080 on a 1M-triangle scene, 1 spp primary rays
 + 1 shadow ray per lit hit (configs[2]), with the render kernel placed against the chip's ceilings.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py --gpus N --steps K --warmup W          (N > 1 without a launcher's environment: starts its own N ranks)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+  python bench.py --config c5 [--gpus N]                   BASELINE.json configs[4]: 5M triangles, 3840x2160, 4 spp path traced, 3 bounces
 
 A step = one frame.  N = 1: one launch of the fused rayGen->traverse->shade->store kernel over the whole frame, scene
 and output resident in HBM.  N > 1: the SAME frame is tile-partitioned (16x16 macro tiles, tile k -> rank k % N),
@@ -39,9 +40,46 @@ HBM_PEAK_GBS = 8000.0     # HBM3E 8 TB/s spec (6.3 TB/s achievable)
 L2_PEAK_GBS = 34500.0     # aggregate L2 bandwidth
 N_SIMDS = 256 * 4         # 256 CUs x 4 SIMD-32
 CLOCK_HZ = 2.4e9          # max engine clock
-VALU_ISSUE_CYCLES = 2.0   # a wave64 VALU instruction occupies its SIMD-32 for 2 cycles ("v_fma_f32 (wave64): 2 cyc")
-W, H = 1920, 1080
-MODE = 100  # Lambert + one shadow ray per light
+# Issue cost of a wave64 vector instruction on one SIMD, measured on the MI355X (tools/micro/valu_cost.hip, 8 wavefronts per SIMD,
+# profiles/r03_valu_cost.txt): v_fma / v_mul / v_add / v_sub / v_mov / v_and / v_or / v_xor / v_add_u32 issue every 2.5 cycles,
+# everything else the kernels use (v_cvt_*, float and integer min / max / med3, compares, v_cndmask, bit-field and all VOP3-only
+# integer forms, SDWA, v_fma_mix, v_perm) every 4.2 -- half rate -- and v_rcp / v_sqrt every 8.2.  The guide's "v_fma_f32
+# (wave64): 2 cyc" is the first class only; round 2 priced every instruction at 2 cycles and under-stated the VALU share.
+VALU_FAST_CYCLES = 2.5
+VALU_SLOW_CYCLES = 4.2
+VALU_TRANS_CYCLES = 8.2
+KERNEL_SOURCES = ("traversal.hip.h", "shading.hip.h", "render_kernels.hip", "path_kernels.hip", "render_kernels.h")
+
+CONFIGS = {
+    # BASELINE.json configs[2]: the configuration the metric is quoted on
+    "c3": {"scene": "heightfield", "w": 1920, "h": 1080, "mode": 100, "kernel": "renderKernel<false, false, LayLegacy>",
+           "what": "1 spp primary + 1 shadow ray per lit hit (mode 100, %d light)"},
+    # BASELINE.json configs[4]
+    "c5": {"scene": "heightfield5m", "w": 3840, "h": 2160, "mode": 200, "spp": 4, "bounces": 3, "seed": 1234, "kernel": "pathKernel<false, LayLegacy>",
+           "what": "4 spp path traced, 3 bounces, 1 shadow ray per light at every diffuse hit (mode 200, %d light)"},
+}
+
+
+def kernel_source_hash():
+    """sha256 over the kernel sources the committed PMC counters were collected for (tools/parse_profile.py stores it)"""
+    import hashlib
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update(open(os.path.join(ROOT, "directx-raytracer_amd", "csrc", name), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` with no launcher environment: start N ranks with torch.distributed.run as a CHILD process and
+    relay its exit code.  Called before torch or anything else has touched a GPU (the parent never does)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, cwd=ROOT)
 
 
 def usable_cores(omp_default):
@@ -56,55 +94,98 @@ def usable_cores(omp_default):
     return max(1, n)
 
 
-def cpu_baseline(oracle, sc, budget_s=10.0):
+def cpu_baseline(oracle, sc, cfg, budget_s=10.0):
     """CPU restatement (the build's own oracle, NOT reference code: the reference has no CPU renderer) of the same
     workload on this host's cores: same scene, same BVH, same arithmetic; OpenMP over image rows.
-    Returns the baseline record and the oracle's RGBA8 frame (the checker for the GPU's timed frame)."""
+    c3: whole frames.  c5: the frame takes the oracle minutes, so the sample is every `stride`-th row of the frame (rows are
+    independent; the stride is chosen so that one pass lasts about the budget).
+    Returns the baseline record, the oracle's RGBA8 frame and the rows of it that are valid (the checker for the GPU's frame)."""
     cam = sc["camera"]
+    W, H, mode = cfg["w"], cfg["h"], cfg["mode"]
     O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
     O.set_width(2)  # binary-tree walk: as fast on the CPU as the 4-wide walk with its SSE slab test (measured within 2 %); same results
     cores = usable_cores(oracle.max_threads())
-    ref = O.render(cam["position"], cam["matrix"], MODE, W, H, want=("rgba8",), n_threads=cores)  # warm caches / thread pool
+    if mode >= 200:
+        oracle.set_path_params(cfg["spp"], cfg["bounces"], cfg["seed"])
+        probe_rows = (0, H, max(1, H // 16))
+        t0 = time.perf_counter()
+        O.render(cam["position"], cam["matrix"], mode, W, H, rows=probe_rows, want=("rgba8",), n_threads=cores)
+        per_row = (time.perf_counter() - t0) / len(range(*probe_rows))
+        stride = max(1, int(np.ceil(per_row * H / max(budget_s, 1.0))))
+        rows = (stride // 2, H, stride)
+        t0 = time.perf_counter()
+        ref = O.render(cam["position"], cam["matrix"], mode, W, H, rows=rows, want=("rgba8",), n_threads=cores)
+        dt = time.perf_counter() - t0
+        st = ref["stats"]
+        rays = st["rays_primary"] + st["rays_shadow"]
+        n_rows = len(range(*rows))
+        rec = {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+               "sample": "%d of the %d rows of the same %dx%d frame (every %d-th row, %d rays, %.1f s), CPU restatement (build's own oracle, "
+                         "not reference code), binary-BVH traversal, gcc -O2 -mfma -ffp-contract=off + OpenMP schedule(dynamic,1 row)"
+                         % (n_rows, H, W, H, stride, rays, dt),
+               "ms_per_frame": dt / n_rows * H * 1e3}
+        return rec, np.ascontiguousarray(ref["rgba8"]).view(np.uint32).reshape(H, W), np.arange(*rows)
+    ref = O.render(cam["position"], cam["matrix"], mode, W, H, want=("rgba8",), n_threads=cores)  # warm caches / thread pool
     frames, rays, t0 = 0, 0, time.perf_counter()
-    while True:
-        st = O.render(cam["position"], cam["matrix"], MODE, W, H, want=("rgba8",), n_threads=cores)["stats"]
+    while budget_s > 0.0:
+        st = O.render(cam["position"], cam["matrix"], mode, W, H, want=("rgba8",), n_threads=cores)["stats"]
         frames += 1
         rays += st["rays_primary"] + st["rays_shadow"]
         dt = time.perf_counter() - t0
         if dt >= budget_s or frames >= 400:
             break
-    rec = {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
-           "sample": "%d full %dx%d frames of the same workload (%.1f s), CPU restatement (build's own oracle, not "
-                     "reference code), binary-BVH traversal, gcc -O2 -mfma -ffp-contract=off + OpenMP schedule(dynamic,1 row)" % (frames, W, H, dt),
-           "ms_per_frame": dt / frames * 1e3}
-    return rec, np.ascontiguousarray(ref["rgba8"]).view(np.uint32).reshape(-1)
+    rec = None
+    if frames:
+        rec = {"value": rays / dt / 1e6, "unit": "Mray/s", "cores": cores, "kind": "port",
+               "sample": "%d full %dx%d frames of the same workload (%.1f s), CPU restatement (build's own oracle, not "
+                         "reference code), binary-BVH traversal, gcc -O2 -mfma -ffp-contract=off + OpenMP schedule(dynamic,1 row)" % (frames, W, H, dt),
+               "ms_per_frame": dt / frames * 1e3}
+    return rec, np.ascontiguousarray(ref["rgba8"]).view(np.uint32).reshape(H, W), np.arange(H)
 
 
-def roofline_block(scene, launch_ms, kernel_ms_median, cnt, alg_bytes):
-    """The render kernel against the chip's ceilings.  Instruction and byte counts per launch come from the committed
+def roofline_block(key, kernel, launch_ms, kernel_ms_median, cnt, alg_bytes):
+    """The dominant kernel against the chip's ceilings.  Instruction and byte counts per launch come from the committed
     rocprofv3 PMC summary of this workload (profiles/roofline_inputs.json, written by tools/parse_profile.py from
     separate --pmc passes as MI355X_MICROARCH.md prescribes; they are properties of the kernel + frame, identical from
-    launch to launch); the launch duration is measured live in this run."""
+    launch to launch); the launch duration is measured live in this run.  The summary records a hash of the kernel sources it
+    was taken for: when the sources have changed since, the counter-derived fields are withheld ("counters_stale")."""
     sec = launch_ms * 1e-3
-    out = {"kernel": "renderKernel<false, false>", "kernel_ms_avg_timed_region": launch_ms, "kernel_ms_event_median": kernel_ms_median,
-           "bound": "valu-issue", "achieved": None, "peak": N_SIMDS * CLOCK_HZ / VALU_ISSUE_CYCLES / 1e9, "unit": "G wave-instructions/s",
+    out = {"kernel": kernel, "kernel_ms_avg_timed_region": launch_ms, "kernel_ms_event_median": kernel_ms_median,
+           "bound": "valu-issue", "achieved": None, "peak": N_SIMDS * CLOCK_HZ / 1e9, "unit": "G SIMD issue cycles/s",
            "frac": None, "traffic": None,
-           "peak_note": "1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
+           "peak_note": "1024 SIMDs x 2.4 GHz; a kernel's issue cycles = sum over its wave64 vector instructions of the measured issue cost "
+                        "of their class (%.1f fma/mul/add/mov/and/or, %.1f conversions/min/max/compare/select/bit-field, %.1f rcp/sqrt: "
+                        "tools/micro/valu_cost.hip)" % (VALU_FAST_CYCLES, VALU_SLOW_CYCLES, VALU_TRANS_CYCLES),
            "logical_bytes_per_launch": alg_bytes, "logical_GBs": alg_bytes / sec / 1e9,
            "logical_note": "64 B x quantised wide-node records fetched + 48 B x triangle records fetched + 4 B x pixels (SURVEY.md 8d): per-ray "
                            "logical fetches, served mostly by the scalar cache, L1, L2 and the Infinity Cache -- NOT an HBM rate, no frac",
            "nodes_fetched": cnt["nodes_visited"], "tris_fetched": cnt["tris_tested"]}
     src = os.path.join(ROOT, "profiles", "roofline_inputs.json")
     try:
-        inp = json.load(open(src)).get(scene)
+        inp = json.load(open(src)).get(key)
     except (OSError, ValueError):
         inp = None
     if inp:
         out["counters_from"] = inp.get("from")
+        if inp.get("kernel_source_hash") != kernel_source_hash():
+            out["counters_stale"] = True  # the kernel that ran is not the kernel that was profiled: no counter-derived figure
+            return out
         if inp.get("valu_insts"):
             out["valu_insts_per_launch"] = inp["valu_insts"]
-            out["achieved"] = inp["valu_insts"] / sec / 1e9
-            out["frac"] = out["achieved"] / out["peak"]
+            fp32 = inp.get("valu_fp32_fma_add_mul_insts")
+            if fp32 is not None:
+                cvt, trans = inp.get("valu_cvt_insts", 0.0), inp.get("valu_trans_insts", 0.0)
+                rest = inp["valu_insts"] - fp32 - cvt - trans  # integer + float min / max / compare / select / move: classes the counters lump
+                known = fp32 * VALU_FAST_CYCLES + cvt * VALU_SLOW_CYCLES + trans * VALU_TRANS_CYCLES
+                lower, upper = known + rest * VALU_FAST_CYCLES, known + rest * VALU_SLOW_CYCLES
+                out["valu_mix"] = {"fp32_fma_add_mul": fp32, "conversions": cvt, "transcendental": trans, "other": rest}
+                out["valu_issue_cycles_per_launch"] = lower
+                out["achieved"] = lower / sec / 1e9
+                out["frac"] = out["achieved"] / out["peak"]
+                out["frac_upper"] = upper / sec / 1e9 / out["peak"]
+                out["frac_note"] = ("`frac` prices the instructions the counters do not classify (integer, float min / max, compares, selects, "
+                                    "moves) at the full rate: a lower bound of the SIMDs' issue cycles; `frac_upper` prices them at half rate "
+                                    "(most of them are: tools/micro/valu_cost.hip) and may exceed 1")
             if inp.get("thread_cycles_valu"):
                 out["lanes_active"] = inp["thread_cycles_valu"] / (inp["valu_insts"] * 64.0)
         if inp.get("hbm_read_bytes") is not None and inp.get("hbm_write_bytes") is not None:
@@ -124,8 +205,10 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--scene", default="heightfield", choices=["heightfield", "soup", "heightfield5m"],
-                    help="heightfield = BASELINE.json configs[2] (the headline); heightfield5m = same view over 4 999 124 triangles "
+    ap.add_argument("--config", default="c3", choices=sorted(CONFIGS), help="c3 = BASELINE.json configs[2], the configuration the metric "
+                    "is quoted on (default); c5 = configs[4]: 5M triangles, 3840x2160, 4 spp path traced, 3 bounces")
+    ap.add_argument("--scene", default=None, choices=["heightfield", "soup", "heightfield5m"],
+                    help="another scene under the chosen config's settings; heightfield5m = the same view over 4 999 124 triangles "
                          "(working set 650 MB > the 256 MB Infinity Cache: the HBM-regime data point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the pipelined / moving-camera / D2H legs (profiling runs)")
@@ -135,9 +218,20 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="N>1 only: frames per launch (1..4) for `value`; default 1")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (RCCL init, tile staging, all-gather, "
                     "de-interleave) with whatever world size the launcher gives, even 1")
-    ap.add_argument("--check-dist-frame", action="store_true", help="N>1 path: compare the gathered frame with the oracle's "
-                    "(tests/test_gpu_parity.py runs this in a child process)")
+    ap.add_argument("--check-dist-frame", action="store_true", help="N>1 path: compare the gathered frame with the oracle's even when "
+                    "the CPU baseline is switched off")
+    ap.add_argument("--spinup-ms", type=float, default=150.0, help="untimed frames before the timed region, by wall time: clocks and "
+                    "caches at their steady state even for a short --steps")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: only with --rendezvous-only (CPU tests)")
+    ap.add_argument("--rendezvous-only", action="store_true", help="the ranks meet, add up their ranks and leave: checks the launch path "
+                    "without a GPU (tests/test_tiling.py)")
     args = ap.parse_args()
+
+    launched = "WORLD_SIZE" in os.environ and "RANK" in os.environ
+    if args.gpus > 1 and not launched:
+        # no launcher set the rank environment: start the N ranks ourselves, as a child process, BEFORE importing torch or
+        # touching a GPU (a process that has initialised the GPU must never be replaced or forked into ranks)
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
@@ -145,10 +239,23 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run --nproc-per-node %d" % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
+    if args.rendezvous_only:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
+        dist.init_process_group(args.backend)
+        t = torch.tensor([rank + 1], dtype=torch.int64)
+        if args.backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            t = t.cuda()
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"rendezvous_ok": int(t.item()) == world * (world + 1) // 2, "n_gpus": world, "backend": args.backend}))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
     torch.cuda.set_device(local_rank)
@@ -164,8 +271,13 @@ def main():
     scenes = importlib.import_module(entry.PKG_NAME + ".scenes")
     host = importlib.import_module(entry.PKG_NAME + ".multigpu")
 
+    cfg = dict(CONFIGS[args.config])
+    if args.scene:
+        cfg["scene"] = args.scene
+    W, H, MODE = cfg["w"], cfg["h"], cfg["mode"]
+    path = MODE >= 200
     sc = {"heightfield": lambda: scenes.heightfield(n_lights=1), "soup": scenes.icosphere_soup,
-          "heightfield5m": lambda: scenes.heightfield(n=1581, n_lights=1)}[args.scene]()
+          "heightfield5m": lambda: scenes.heightfield(n=1581, n_lights=1)}[cfg["scene"]]()
     n_tris = sum(len(m["triangles"]) for m in sc["meshes"])
     cam = sc["camera"]
     r = pkg.Renderer(local_rank)
@@ -174,10 +286,13 @@ def main():
     upload_s = time.perf_counter() - t0
     r.set_camera(cam["position"], cam["matrix"])
     r.change_shading_mode(MODE)
+    if path:
+        r.set_path_params(cfg["spp"], cfg["bounces"], cfg["seed"])
     main_stream = torch.cuda.current_stream()
     r.set_stream(main_stream.cuda_stream)  # the kernels run on torch streams: torch events and RCCL order with them
 
     frame0 = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     # instrumented variant, once, untimed: exact ray / node / triangle counts of the whole frame
     r.set_counting(True)
     cnt = r.render_frame_device(W, H, frame0.data_ptr(), stats=True)
@@ -195,9 +310,10 @@ def main():
 
     def policy(n_fly, batch):
         """Build the per-frame step of one pipelining policy: n_fly launches in flight (alternating streams and buffers),
-        `batch` frames per launch (N > 1 only).  Returns (step, set_total, streams, last_frame)."""
+        `batch` frames per launch (N > 1 only).  Returns (step, state, streams); state["gather_us"] collects the event-timed
+        all-gather + de-interleave of the launches when state["time_gather"] is set."""
         streams = [main_stream] + [torch.cuda.Stream() for _ in range(n_fly - 1)]
-        state = {"total": 0, "launches": 0, "last": None}
+        state = {"total": 0, "launches": 0, "last": None, "time_gather": False, "gather_ev": []}
         if not multi:
             frames = [frame0] + [torch.zeros(W * H, dtype=torch.int32, device="cuda") for _ in range(n_fly - 1)]
 
@@ -222,18 +338,45 @@ def main():
                 r.set_stream(streams[k].cuda_stream)
                 with torch.cuda.stream(streams[k]):
                     r.render_tiles_batch_device(W, H, rank, world, [staging[k].data_ptr() + 4 * per * f for f in range(nb)])
+                    if state["time_gather"]:
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record(streams[k])
                     host.gather_batch(staging[k][:nb * per], W, H, nb,
                                       lambda g, f, k=k, nb=nb: (r.untile_batch_device(W, H, world, nb, f, g.data_ptr(), out[k][f].data_ptr()), out[k][f])[1],
                                       gathered[k][:world * nb * per])
+                    if state["time_gather"]:
+                        e1.record(streams[k])
+                        state["gather_ev"].append((e0, e1))
                 state["last"] = out[k][nb - 1]
         return step, state, streams
 
     def timed(step, state, streams, steps, warmup):
-        state["total"] = warmup
-        for i in range(warmup):
+        state["total"] = 1 << 30
+        i = 0
+        t_spin = time.perf_counter()
+        # untimed: the --warmup steps, then more until --spinup-ms of wall time have passed (same count on every rank: the
+        # count is agreed on below), so that a short timed region starts at the steady state
+        while i < warmup:
             step(i)
+            i += 1
+        torch.cuda.synchronize()
+        extra = 0
+        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms and extra < 4096:
+            for _ in range(8):
+                step(i)
+                i += 1
+            extra += 8
+            torch.cuda.synchronize()
+        if multi:  # every rank issues the same number of collectives: take the largest spin-up count
+            n_extra = torch.tensor([extra], dtype=torch.int64, device="cuda")
+            dist.all_reduce(n_extra, op=dist.ReduceOp.MAX)
+            while extra < int(n_extra.item()):
+                step(i)
+                i += 1
+                extra += 1
         fence()
         state["total"] = steps
+        state["launches"] = 0
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
         ev0.record(main_stream)
@@ -250,41 +393,53 @@ def main():
             tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
-        return elapsed, stream_ms
+        return elapsed, stream_ms, warmup + extra
 
     n_fly = max(1, args.inflight)
     batch = max(1, min(4, args.batch)) if multi else 1
     step, state, streams = policy(n_fly, batch)
-    if n_fly == 1:
+    if n_fly == 1 and not path:
         # scene setup, like the BVH build: the launch order of an unchanged view settles after each of the library's 4 scratch
         # slots has measured the view twice (crt_api.cpp); done here so that any --warmup, even 0, times the settled state
         state["total"] = 12
         for i in range(12):
             step(i)
         fence()
-    elapsed, stream_ms = timed(step, state, streams, args.steps, args.warmup)
-    last_frame = state["last"].cpu().numpy().view(np.uint32) if rank == 0 else None
+    elapsed, stream_ms, untimed_steps = timed(step, state, streams, args.steps, args.warmup)
+    last_frame = state["last"].cpu().numpy().view(np.uint32).reshape(H, W) if rank == 0 else None
 
     # own-kernel share of this rank, measured per launch with the library's HIP events (render kernel only)
     kms = []
     scratch = torch.zeros(per, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
     for _ in range(min(20, args.steps)):
         if not multi:
             kms.append(r.render_frame_device(W, H, frame0.data_ptr(), stats=True)["kernel_ms"])
         else:
             kms.append(r.render_tiles_device(W, H, rank, world, scratch.data_ptr(), stats=True)["kernel_ms"])
     kernel_ms = float(np.median(kms))
+    gather_us = None
+    if multi:
+        # the frame-end exchange of this rank, event-timed: ONE all-gather of the staged tiles + the de-interleave kernel
+        gstep, gstate, gstreams = policy(1, 1)
+        gstate["total"] = 1 << 30
+        gstate["time_gather"] = True
+        for i in range(min(20, max(4, args.steps))):
+            gstep(i)
+        fence()
+        gather_us = float(np.median([a.elapsed_time(b) for a, b in gstate["gather_ev"]])) * 1e3
+        r.set_stream(main_stream.cuda_stream)
 
     extras = {}
     if not args.no_extras:
         # throughput policy, labelled extra: 4 launches in flight on alternating streams; from 8 ranks up 2 frames per launch
         p_fly, p_batch = 4, (2 if (multi and world >= 8) else 1)
         pstep, pstate, pstreams = policy(p_fly, p_batch)
-        p_elapsed, _ = timed(pstep, pstate, pstreams, args.steps, max(args.warmup, 8))
+        p_elapsed, _, _ = timed(pstep, pstate, pstreams, args.steps, max(args.warmup, 8))
         extras["pipelined"] = {"launches_in_flight": p_fly, "frames_per_launch": p_batch, "ms_per_frame": p_elapsed / args.steps * 1e3,
                                "value": rays_per_frame * args.steps / p_elapsed / 1e6, "unit": "Mray/s",
                                "note": "throughput policy; `value` above uses 1 launch in flight, 1 frame per launch at every N"}
-    if not args.no_extras and not multi:
+    if not args.no_extras and not multi and not path:
         # a camera that moves every frame (0.01 degrees of orbit: practically the same view, so the difference to the static
         # figure is the cost of measuring and sorting the launch order for every frame, as an interactive viewer pays it)
         pos0 = np.float32(cam["position"])
@@ -324,17 +479,18 @@ def main():
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = rays_per_frame * args.steps / elapsed / 1e6
+        scene_name = {"heightfield": "seeded height field 708x708 quads + ground quad (BASELINE.json configs[2])",
+                      "heightfield5m": "seeded height field 1581x1581 quads + ground quad" + (" (BASELINE.json configs[4])" if path else ""),
+                      "soup": "seeded soup of 3125 copied icospheres + ground quad"}[cfg["scene"]]
         line = {
             "metric": "Mray/s", "value": value, "unit": "Mray/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, %d triangles, %dx%d, 1 spp primary + 1 shadow ray per lit hit (mode 100, %d light)"
-                                   % ({"heightfield": "seeded height field 708x708 quads + ground quad (BASELINE.json configs[2])",
-                                       "heightfield5m": "seeded height field 1581x1581 quads + ground quad",
-                                       "soup": "seeded soup of 3125 copied icospheres + ground quad"}[args.scene], n_tris, W, H, len(sc["lights"])),
-                       "rays_per_frame": rays_per_frame, "primary_rays": cnt["rays_primary"], "shadow_rays": cnt["rays_shadow"],
+            "config": {"workload": "%s, %d triangles, %dx%d, %s" % (scene_name, n_tris, W, H, cfg["what"] % len(sc["lights"])),
+                       "rays_per_frame": rays_per_frame, "closest_hit_rays": cnt["rays_primary"], "shadow_rays": cnt["rays_shadow"],
                        "frames_in_flight": n_fly * batch, "launches_in_flight": n_fly, "frames_per_launch": batch,
-                       "camera": "static (launch order of the unchanged view settled before the timed region); moving camera: moving_camera_ms_per_frame",
+                       "untimed_steps_before_the_timed_region": untimed_steps,
+                       "camera": "static" + ("" if path else " (launch order of the unchanged view settled before the timed region); moving camera: moving_camera_ms_per_frame"),
                        "parallelism": "1 GPU, one launch per frame" if world == 1 else "framebuffer tiles 16x16 round-robin over %d GPUs + 1 RCCL all-gather/frame" % world,
                        "bvh": {"nodes": r.bvh_info()["n_nodes"], "max_depth": r.bvh_info()["max_depth"], "build_and_upload_s": upload_s}},
             "ms_per_frame": ms_per_step,
@@ -342,25 +498,30 @@ def main():
         }
         line.update(extras)
         if not multi:
-            # dominant (only) kernel: renderKernel<false, false>.  Its average launch duration = HIP events on its stream around
-            # the K back-to-back launches of the timed region / K (with 1 launch in flight the stream holds nothing else: the
-            # 1-workgroup sortUnitsKernel that orders a later frame's launch runs on a side stream)
+            # dominant (only) kernel.  Its average launch duration = HIP events on its stream around the K back-to-back launches
+            # of the timed region / K (with 1 launch in flight the stream holds nothing else: the 1-workgroup sortUnitsKernel
+            # that orders a later frame's launch runs on a side stream)
             launch_ms = stream_ms / args.steps if n_fly == 1 else kernel_ms
-            line["roofline"] = roofline_block(args.scene, launch_ms, kernel_ms, cnt, alg_bytes_frame)
+            key = args.config if not args.scene else "%s:%s" % (args.config, args.scene)
+            line["roofline"] = roofline_block(key, cfg["kernel"], launch_ms, kernel_ms, cnt, alg_bytes_frame)
         else:
             line["rank0_render_kernel_ms"] = kernel_ms
-        want_check = (not multi and not args.no_cpu_baseline) or args.check_dist_frame
+            line["rank0_gather_untile_us"] = gather_us
+            line["message_bytes_per_rank"] = per * 4
+        want_check = not args.no_cpu_baseline or args.check_dist_frame
         if want_check:
-            base, ref = cpu_baseline(entry.load_oracle(), sc, budget_s=10.0 if not multi else 0.0)
-            if not multi:
+            budget = 0.0 if (multi or args.no_cpu_baseline) else (20.0 if path else 10.0)
+            base, ref, rows = cpu_baseline(entry.load_oracle(), sc, cfg, budget_s=budget if not path else max(budget, 6.0))
+            if not multi and not args.no_cpu_baseline and base:
                 line["cpu_baseline"] = base
                 line["speedup_vs_cpu_baseline"] = value / base["value"]
-            # the timed frame is the frame the oracle renders: RGBA8 identical, pixel for pixel
-            ok = bool(np.array_equal(last_frame, ref))
+            # the timed frame is the frame the oracle renders: RGBA8 identical, pixel for pixel (c5: on the sampled rows)
+            ok = bool(np.array_equal(last_frame[rows], ref[rows]))
             line["frame_matches_oracle"] = ok
+            line["frame_rows_checked"] = int(len(rows))
             if not ok:
-                line["frame_mismatching_pixels"] = int((last_frame != ref).sum())
-        print(json.dumps(line))
+                line["frame_mismatching_pixels"] = int((last_frame[rows] != ref[rows]).sum())
+        print(json.dumps(line), flush=True)
     if multi:
         dist.barrier()
         dist.destroy_process_group()

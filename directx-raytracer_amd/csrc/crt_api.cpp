@@ -119,8 +119,18 @@ struct crt_ctx {
     unsigned long long* dCounters = nullptr;
     int* dSpill[kRing] = {};          // traversal-stack spill arenas (traversal.hip.h Stack), one per ring slot
     size_t spillBytes[kRing] = {};
-    unsigned char* dPathScratch[kRing] = {}; // mode 200: queues of the wavefront-private path pipeline, one set per ring slot
-    size_t pathScratchBytes[kRing] = {};
+    // mode 200: scratch of the persistent path kernel (one region per RESIDENT workgroup + the launch's work counter).  An arena
+    // belongs to the stream that last used it: frames issued on one stream run one after the other and share ONE arena; only
+    // frames on different streams (up to kRing in flight) get arenas of their own.
+    struct PathArena {
+        unsigned char* mem = nullptr;
+        size_t bytes = 0;
+        hipStream_t stream = nullptr;
+        bool used = false;       // `stream` is meaningful
+        hipEvent_t lastUse = nullptr;
+        bool pending = false;    // lastUse recorded
+        uint32_t serial = 0;     // frameSerial of the last use (least recently used arena is taken over by a new stream)
+    } pathArena[kRing];
     unsigned long long* dTimeline = nullptr; // diagnostic: 3 words per workgroup, counting variant only
     size_t timelineWords = 0;
     bool wantTimeline = false;
@@ -261,7 +271,10 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         // deepest stack a ray can build: three pending siblings per wide level; what does not fit the LDS part spills
         const uint32_t deepest = c->bvh.width ? (c->bvh.width - 1u) * c->bvh.depthWide + 1u : 3u * c->bvh.depth4 + 1u;
         p.spill_stride = deepest > p.stack_entries ? deepest - p.stack_entries : 1u;
-        const size_t need = static_cast<size_t>(crt::renderUnitCount(p)) * p.n_batch * 64u * p.spill_stride * sizeof(int);
+        // (mode 200: one slice per resident workgroup of the persistent kernel)
+        if (p.mode >= 200u) p.path_tile = c->tunePathTile ? c->tunePathTile : 8u;
+        const size_t groups = p.mode >= 200u ? static_cast<size_t>(crt::pathGridSize(p)) : static_cast<size_t>(crt::renderUnitCount(p)) * p.n_batch;
+        const size_t need = groups * 64u * p.spill_stride * sizeof(int);
         if (c->spillBytes[slot] < need) {
             HIP_TRY(c, hipDeviceSynchronize());
             if (c->dSpill[slot]) (void)hipFree(c->dSpill[slot]);
@@ -272,23 +285,40 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         }
         p.spill = c->dSpill[slot];
     }
+    crt_ctx::PathArena* arena = nullptr;
     if (p.mode >= 200u) {
-        // path tracing: every workgroup streams the paths of its pixel tile through private queues in HBM.  One 8x8 packet x up to
-        // 16 samples per workgroup (256 paths at 4 spp) measured best at every frame size -- 6.6 vs 10.1 ms on C3 at 1080p, 27.3 vs
-        // 29.2 ms on C5 at 4K against one 16x16 macro tile x 4 samples: more, smaller workgroups balance better than longer queues
+        // path tracing: resident wavefronts stream the paths of one pixel tile after the other through private queues in HBM.  One
+        // 8x8 packet x up to 16 samples per work item (256 paths at 4 spp) measured best at every frame size -- 6.6 vs 10.1 ms on C3
+        // at 1080p, 27.3 vs 29.2 ms on C5 at 4K against one 16x16 macro tile x 4 samples
         p.path_tile = c->tunePathTile ? c->tunePathTile : 8u;
         p.path_samples = std::min<uint32_t>(p.path_tile == 16u ? 4u : 16u, std::max<uint32_t>(1u, p.spp));
         p.path_region_bytes = crt::pathRegionBytes(p.path_tile, p.path_samples);
-        const size_t need = static_cast<size_t>(crt::pathWorkgroupCount(p)) * p.path_region_bytes;
-        if (c->pathScratchBytes[slot] < need) {
-            HIP_TRY(c, hipDeviceSynchronize());
-            if (c->dPathScratch[slot]) (void)hipFree(c->dPathScratch[slot]);
-            c->dPathScratch[slot] = nullptr;
-            c->pathScratchBytes[slot] = 0;
-            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&c->dPathScratch[slot]), need));
-            c->pathScratchBytes[slot] = need;
+        p.path_work_items = crt::pathWorkgroupCount(p);
+        const size_t kHead = 256; // the work counter lives in front of the regions
+        const size_t need = kHead + static_cast<size_t>(crt::pathGridSize(p)) * p.path_region_bytes;
+        // the arena this stream used last; else an unused one; else the least recently used one of another stream
+        for (auto& a : c->pathArena)
+            if (a.used && a.stream == c->stream) arena = &a;
+        if (!arena) {
+            for (auto& a : c->pathArena)
+                if (!arena || (!a.used && arena->used) || (a.used == arena->used && a.serial < arena->serial)) arena = &a;
+            if (arena->pending && hipEventQuery(arena->lastUse) != hipSuccess) HIP_TRY(c, hipStreamWaitEvent(c->stream, arena->lastUse, 0));
+            arena->stream = c->stream;
+            arena->used = true;
         }
-        p.path_scratch = c->dPathScratch[slot];
+        if (arena->bytes < need) {
+            HIP_TRY(c, hipDeviceSynchronize());
+            if (arena->mem) (void)hipFree(arena->mem);
+            arena->mem = nullptr;
+            arena->bytes = 0;
+            HIP_TRY(c, hipMalloc(reinterpret_cast<void**>(&arena->mem), need));
+            arena->bytes = need;
+        }
+        if (!arena->lastUse) HIP_TRY(c, hipEventCreateWithFlags(&arena->lastUse, hipEventDisableTiming));
+        arena->serial = c->frameSerial;
+        p.path_counter = reinterpret_cast<uint32_t*>(arena->mem);
+        p.path_scratch = arena->mem + kHead;
+        HIP_TRY(c, hipMemsetAsync(p.path_counter, 0, sizeof(uint32_t), c->stream));
     }
     // Cost feedback: the lifetimes frame f's wavefronts report are sorted on a side stream while the next frames render and
     // order the launch of frame f + kRing (same ring slot), so neither the sort nor the dependency on an earlier frame
@@ -354,6 +384,10 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
     if (stats) HIP_TRY(c, hipEventRecord(c->evStop, c->stream)); // kernel_ms = the render kernel alone
     HIP_TRY(c, hipEventRecord(c->evRender[slot], c->stream));
     c->renderPending[slot] = true;
+    if (arena) {
+        HIP_TRY(c, hipEventRecord(arena->lastUse, c->stream));
+        arena->pending = true;
+    }
     if (feedback) {
         hipStream_t ss = c->sideStream;
         HIP_TRY(c, hipStreamWaitEvent(ss, c->evRender[slot], 0));
@@ -474,7 +508,8 @@ void crt_destroy(crt_ctx* c)
     if (c->dTexels) (void)hipFree(c->dTexels);
     for (int i = 0; i < crt_ctx::kRing; i++) {
         if (c->dSpill[i]) (void)hipFree(c->dSpill[i]);
-        if (c->dPathScratch[i]) (void)hipFree(c->dPathScratch[i]);
+        if (c->pathArena[i].mem) (void)hipFree(c->pathArena[i].mem);
+        if (c->pathArena[i].lastUse) (void)hipEventDestroy(c->pathArena[i].lastUse);
     }
     if (c->sideStream) (void)hipStreamSynchronize(c->sideStream);
     for (int i = 0; i < crt_ctx::kRing; i++) {

@@ -10,7 +10,9 @@
 // RCCL all-gather per frame (crt_render_frame_distributed); rank 0 prints and writes the images.
 #include "renderer.h"
 
+#include <signal.h>
 #include <sys/wait.h>
+#include <time.h>
 #include <unistd.h>
 
 #include <cstdio>
@@ -46,6 +48,7 @@ struct Args {
     int spp = -1, bounces = -1, seed = -1, phongKs = -1, phongExp = -1;
     float orbit = 0.f, pitch = 0.f, forward = 0.f, right = 0.f, zoom = 0.f;
     bool count = false;
+    unsigned long long nonce = 0; // names the launch in the id file (set by the --ranks parent)
     std::map<int, uint32_t> modeAt;
 };
 
@@ -85,7 +88,7 @@ int runRank(const Args& a)
     if (a.seed >= 0) renderer.setOption("seed", a.seed);
     if (a.phongKs >= 0) renderer.setOption("phong_ks", a.phongKs);
     if (a.phongExp >= 0) renderer.setOption("phong_exponent", a.phongExp);
-    if (a.ranks > 0) renderer.joinRanks(static_cast<uint32_t>(a.rank), static_cast<uint32_t>(a.ranks), a.idFile);
+    if (a.ranks > 0) renderer.joinRanks(static_cast<uint32_t>(a.rank), static_cast<uint32_t>(a.ranks), a.idFile, a.nonce);
     const bool talk = a.ranks <= 0 || a.rank == 0;
     std::vector<std::string> script;
     if (!a.pathFile.empty()) {
@@ -126,22 +129,37 @@ int runRank(const Args& a)
     return 0;
 }
 
-// parent of an N-rank run: starts the rank processes BEFORE anything here touches the GPU, waits for all of them
+// parent of an N-rank run: starts the rank processes BEFORE anything here touches the GPU and waits for them.  The first rank
+// that fails (non-zero exit or a signal: bad device index, scene that does not load, out of memory) ends the run: its peers
+// would otherwise sit in ncclCommInitRank / ncclAllGather for good, so they are sent SIGTERM, then SIGKILL, and the parent
+// reports which rank went first.  (Ending the children is all that happens: nothing that has touched a GPU is re-executed.)
 int launchRanks(const Args& a, int argc, char** argv)
 {
     std::string idFile = a.idFile;
     if (idFile.empty()) idFile = "/tmp/crt_render_comm_" + std::to_string(static_cast<long>(getpid())) + ".id";
-    std::remove(idFile.c_str());
+    std::remove(idFile.c_str()); // whatever an earlier run left under this name ...
+    struct timespec ts;
+    clock_gettime(CLOCK_REALTIME, &ts);
+    // ... and a per-launch nonce in the file, for ranks that find a file another launch writes under the same name
+    const unsigned long long nonce = (static_cast<unsigned long long>(ts.tv_sec) << 30) ^ static_cast<unsigned long long>(ts.tv_nsec) ^
+                                     (static_cast<unsigned long long>(getpid()) << 44) ^ 1ull;
     std::vector<pid_t> kids;
     for (int r = 0; r < a.ranks; r++) {
         const pid_t pid = fork();
-        if (pid < 0) { std::perror("fork"); return 1; }
+        if (pid < 0) {
+            std::perror("fork");
+            for (pid_t k : kids) kill(k, SIGKILL);
+            for (pid_t k : kids) waitpid(k, nullptr, 0);
+            return 1;
+        }
         if (pid == 0) {
             std::vector<std::string> args(argv, argv + argc);
             args.push_back("--rank");
             args.push_back(std::to_string(r));
             args.push_back("--id-file");
             args.push_back(idFile);
+            args.push_back("--nonce");
+            args.push_back(std::to_string(nonce));
             std::vector<char*> cargs;
             for (std::string& s : args) cargs.push_back(s.data());
             cargs.push_back(nullptr);
@@ -152,9 +170,34 @@ int launchRanks(const Args& a, int argc, char** argv)
         kids.push_back(pid);
     }
     int rc = 0;
-    for (pid_t pid : kids) {
+    size_t left = kids.size();
+    while (left > 0) {
         int status = 0;
-        if (waitpid(pid, &status, 0) < 0 || !WIFEXITED(status) || WEXITSTATUS(status) != 0) rc = 1;
+        const pid_t pid = waitpid(-1, &status, 0);
+        if (pid < 0) { rc = 1; break; }
+        size_t who = 0;
+        while (who < kids.size() && kids[who] != pid) who++;
+        if (who == kids.size()) continue; // not one of ours
+        kids[who] = -1;
+        left--;
+        const bool good = WIFEXITED(status) && WEXITSTATUS(status) == 0;
+        if (good || rc != 0) continue;
+        rc = 1;
+        if (WIFSIGNALED(status)) std::fprintf(stderr, "crt_render: rank %zu ended by signal %d; stopping the other ranks\n", who, WTERMSIG(status));
+        else std::fprintf(stderr, "crt_render: rank %zu exited with code %d; stopping the other ranks\n", who, WIFEXITED(status) ? WEXITSTATUS(status) : -1);
+        for (pid_t k : kids)
+            if (k > 0) kill(k, SIGTERM);
+        for (int waited = 0; waited < 200 && left > 0; waited++) { // up to 2 s to leave on their own
+            for (size_t i = 0; i < kids.size(); i++) {
+                if (kids[i] > 0 && waitpid(kids[i], nullptr, WNOHANG) == kids[i]) {
+                    kids[i] = -1;
+                    left--;
+                }
+            }
+            if (left > 0) usleep(10000);
+        }
+        for (pid_t k : kids)
+            if (k > 0) kill(k, SIGKILL);
     }
     std::remove(idFile.c_str());
     return rc;
@@ -198,6 +241,7 @@ int main(int argc, char** argv)
         else if (s == "--rank") a.rank = std::atoi(next("--rank"));
         else if (s == "--device-base") a.deviceBase = std::atoi(next("--device-base"));
         else if (s == "--id-file") a.idFile = next("--id-file");
+        else if (s == "--nonce") a.nonce = std::strtoull(next("--nonce"), nullptr, 10);
         else { usage(); return 2; }
     }
     if (a.frames < 1 || a.ranks < 0 || a.ranks > 64) { usage(); return 2; }

@@ -265,16 +265,51 @@ __device__ __forceinline__ void streamShade(const RenderParams& p, const float4*
 #ifndef CRT_PATH_WAVES_PER_EU
 #define CRT_PATH_WAVES_PER_EU 5
 #endif
+// Persistent wavefronts: the grid is what the chip can hold at once (pathGridSize), and every workgroup takes pixel tiles from
+// a shared counter until none is left.  Scratch (queues, stack spill arena) therefore belongs to the RESIDENT workgroup, not to
+// the tile: 5120 regions instead of 130 560 at 3840x2160 (3.9 GB -> 152 MB at 4 spp), and a workgroup that finishes a cheap
+// tile goes on with the next one instead of leaving its wave slot to a fresh launch.  Every wavefront reaches the exit: the
+// counter only grows, and a value >= n_work ends the loop.
 template <bool COUNT, class L>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAVES_PER_EU, 8))) void pathKernel(const RenderParams p)
 {
     extern __shared__ int s_stack[];
-    const uint32_t frame = p.n_batch > 1u ? blockIdx.x % p.n_batch : 0u;
-    const uint32_t wg = p.n_batch > 1u ? blockIdx.x / p.n_batch : blockIdx.x;
-    const bool big = p.path_tile == 16u;                  // workgroup = whole macro tile (four 8x8 packets per sample) or one 8x8 packet
-    const uint32_t j = big ? wg : wg >> 2;                // position of the macro tile in this rank's list
-    const uint32_t subFirst = big ? 0u : (wg & 3u), subCount = big ? 4u : 1u;
+    const bool big = p.path_tile == 16u;                  // work item = whole macro tile (four 8x8 packets per sample) or one 8x8 packet
+    const uint32_t subCount = big ? 4u : 1u;
     const uint32_t tilePixels = subCount * 64u;
+    const uint32_t nWork = p.path_work_items;
+    uint32_t cntNodes = 0, cntTris = 0, cntShadow = 0, cntClosest = 0, iters = 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const float4* nodes = reinterpret_cast<const float4*>(p.nodes);
+    const float4* tris = reinterpret_cast<const float4*>(p.tris);
+    Stack stack;
+    stack.lds = s_stack + lane;
+    stack.spill = p.spill + (static_cast<size_t>(blockIdx.x) * 64u + lane) * p.spill_stride;
+    stack.cap = static_cast<int>(p.stack_entries);
+    stack.sp = 0;
+    const int innerMin = static_cast<int>(p.tune_inner_min);
+    PathScratch q;
+    q.B = tilePixels * p.path_samples;
+    {
+        float4* base = reinterpret_cast<float4*>(p.path_scratch + static_cast<size_t>(blockIdx.x) * p.path_region_bytes);
+        q.shade = base;
+        q.trace = q.shade + static_cast<size_t>(kShadePlanes) * q.B;
+        q.done = q.trace + static_cast<size_t>(kTracePlanes) * q.B;
+        q.thr = q.done + q.B;
+        q.accum = q.thr + q.B;
+    }
+    const F3 miss = f3(p.miss[0], p.miss[1], p.miss[2]);
+  for (;;) {
+    uint32_t item = 0;
+    if (lane == 0) item = atomicAdd(p.path_counter, 1u);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= nWork) break;
+    iters = 0; // the raised issue priority of a long tile (kBoostAfter) ends with it
+    __builtin_amdgcn_s_setprio(0);
+    const uint32_t frame = p.n_batch > 1u ? item % p.n_batch : 0u;
+    const uint32_t wg = p.n_batch > 1u ? item / p.n_batch : item;
+    const uint32_t j = big ? wg : wg >> 2;                // position of the macro tile in this rank's list
+    const uint32_t subFirst = big ? 0u : (wg & 3u);
     const float* camPos = frame ? p.batch_pos[frame - 1u] : p.pos;
     const float* camRot = frame ? p.batch_rot[frame - 1u] : p.rot;
     uint32_t* outRgba8 = frame ? p.batch_rgba8[frame - 1u] : p.rgba8;
@@ -292,30 +327,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
         tile_x = k % p.tiles_x;
         tile_y = k / p.tiles_x;
     }
-    if (!valid) return;
-
-    const uint32_t lane = threadIdx.x & 63u;
-    const float4* nodes = reinterpret_cast<const float4*>(p.nodes);
-    const float4* tris = reinterpret_cast<const float4*>(p.tris);
-    Stack stack;
-    stack.lds = s_stack + lane;
-    stack.spill = p.spill + (static_cast<size_t>(blockIdx.x) * 64u + lane) * p.spill_stride;
-    stack.cap = static_cast<int>(p.stack_entries);
-    stack.sp = 0;
-    const int innerMin = static_cast<int>(p.tune_inner_min);
-
-    PathScratch q;
-    q.B = tilePixels * p.path_samples;
-    {
-        float4* base = reinterpret_cast<float4*>(p.path_scratch + static_cast<size_t>(blockIdx.x) * p.path_region_bytes);
-        q.shade = base;
-        q.trace = q.shade + static_cast<size_t>(kShadePlanes) * q.B;
-        q.done = q.trace + static_cast<size_t>(kTracePlanes) * q.B;
-        q.thr = q.done + q.B;
-        q.accum = q.thr + q.B;
-    }
-    const F3 miss = f3(p.miss[0], p.miss[1], p.miss[2]);
-    uint32_t cntNodes = 0, cntTris = 0, cntShadow = 0, cntClosest = 0, iters = 0;
+    if (!valid) continue;
 
     for (uint32_t s0 = 0; s0 < p.spp; s0 += p.path_samples) {
         const uint32_t nS = min(p.path_samples, p.spp - s0);
@@ -408,6 +420,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
             }
         }
     }
+  } // next work item
     if (COUNT) {
         const uint32_t a = waveSum(cntNodes), c = waveSum(cntTris), sh = waveSum(cntShadow), cl = waveSum(cntClosest);
         if (lane == 0) {
@@ -421,8 +434,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
 
 } // namespace
 
-// scratch the path-tracing pipeline needs per workgroup (one macro tile): the two queues, the finished-path radiances and
-// the cross-pass sums; and how many workgroups launchRender starts for p in mode 200
+// scratch the path-tracing pipeline needs per resident workgroup: the two queues, the finished-path radiances and the cross-pass
+// sums; how many work items (pixel tiles x frames of a batch) a launch has; and how many workgroups it starts
 size_t pathRegionBytes(uint32_t tile, uint32_t samples_per_pass)
 {
     const size_t pixels = static_cast<size_t>(tile) * tile, B = pixels * samples_per_pass;
@@ -430,10 +443,34 @@ size_t pathRegionBytes(uint32_t tile, uint32_t samples_per_pass)
 }
 uint32_t pathWorkgroupCount(const RenderParams& p) { return renderUnitCount(p) / (p.path_tile == 16u ? 4u : 1u) * (p.n_batch ? p.n_batch : 1u); }
 
+// resident workgroups of the persistent kernel: what the occupancy calculator allows per CU (registers, LDS) x CUs.  An estimate
+// that is one too high per CU only means a few workgroups start late and find the counter exhausted; nothing waits on them.
+uint32_t pathGridSize(const RenderParams& p)
+{
+    static int perCu = 0, cus = 0;
+    if (perCu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        const size_t lds = static_cast<size_t>(kStackEntries) * 64u * sizeof(int); // worst case LDS: the grid must fit any stack_entries
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, reinterpret_cast<const void*>(&pathKernel<false, LayLegacy>), 64, lds) != hipSuccess || perCu <= 0) {
+            perCu = 16;
+            cus = 256;
+        } else {
+            cus = prop.multiProcessorCount;
+        }
+        perCu = perCu > 32 ? 32 : perCu;
+    }
+    const uint32_t cap = static_cast<uint32_t>(perCu) * static_cast<uint32_t>(cus);
+    const uint32_t work = pathWorkgroupCount(p);
+    return work < cap ? work : cap;
+}
+
 int launchPath(const RenderParams& p, bool counting, ihipStream_t* stream)
 {
-    // one wavefront per pixel tile carries all its paths through the pipeline
-    const dim3 grid(pathWorkgroupCount(p)), block(64);
+    // one wavefront per resident slot carries the paths of one pixel tile after the other through the pipeline
+    if (!p.path_counter || p.path_work_items == 0) return static_cast<int>(hipErrorInvalidValue);
+    const dim3 grid(pathGridSize(p)), block(64);
     const size_t lds = static_cast<size_t>(p.stack_entries) * 64u * sizeof(int);
 #define CRT_LAUNCH(LAY)                                                                                \
     if (counting) hipLaunchKernelGGL((pathKernel<true, LAY>), grid, block, lds, stream, p);            \

@@ -64,7 +64,9 @@ struct RenderParams {
     float batch_rot[3][9];
     uint32_t* batch_rgba8[3];
     // mode 200: per-workgroup scratch of the wavefront-private path pipeline (path_kernels.hip pathKernel)
-    unsigned char* path_scratch;  // pathWorkgroupCount() regions of path_region_bytes
+    unsigned char* path_scratch;  // pathGridSize() regions of path_region_bytes: one per RESIDENT workgroup of the persistent kernel
+    uint32_t* path_counter;       // work-item counter of the launch (zeroed on the stream before it)
+    uint32_t path_work_items;     // pathWorkgroupCount(): pixel tiles x frames of the batch
     size_t path_region_bytes;     // pathRegionBytes(path_samples)
     uint32_t path_tile;           // 16: one workgroup per 16x16 macro tile; 8: one per 8x8 packet
     uint32_t path_samples;        // samples of the tile carried through the pipeline together: B = tile^2 x this paths (<= 1024)
@@ -80,6 +82,7 @@ int launchPath(const RenderParams& p, bool counting, ihipStream_t* stream);
 // mode 200 scratch sizing
 size_t pathRegionBytes(uint32_t tile, uint32_t samples_per_pass);
 uint32_t pathWorkgroupCount(const RenderParams& p);
+uint32_t pathGridSize(const RenderParams& p); // workgroups the persistent path kernel starts: min(work items, what the chip holds at once)
 // unit_cost -> unit_order (descending)
 int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, bool xcdAffine, ihipStream_t* stream);
 // tile-major gathered buffer -> row-major frame

@@ -101,7 +101,10 @@ void Renderer::setOption(const char* name, int value)
     check(crt_set_option(ctx, name, value), name);
 }
 
-void Renderer::joinRanks(uint32_t rankIn, uint32_t nRanksIn, const std::string& idFile)
+// The id file holds {nonce, communicator id}.  The nonce names the launch (crt_render --ranks draws a fresh one per run): a file
+// left behind by an earlier run, or by another launch that was given the same path, carries a different nonce and is waited out
+// like a file that is not there yet instead of being taken for this run's id (ranks joining a dead communicator block for good).
+void Renderer::joinRanks(uint32_t rankIn, uint32_t nRanksIn, const std::string& idFile, unsigned long long nonce)
 {
     if (!ctx) throw std::runtime_error("joinRanks before prepareForRendering");
     unsigned char id[CRT_COMM_ID_BYTES];
@@ -109,20 +112,22 @@ void Renderer::joinRanks(uint32_t rankIn, uint32_t nRanksIn, const std::string& 
         if (crt_comm_unique_id(id) != CRT_OK) throw std::runtime_error(std::string("crt_comm_unique_id: ") + crt_last_error(nullptr));
         const std::string tmp = idFile + ".tmp";
         FILE* f = std::fopen(tmp.c_str(), "wb");
-        if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id)) throw std::runtime_error("cannot write '" + tmp + "'");
-        std::fclose(f);
+        const bool ok = f && std::fwrite(&nonce, 1, sizeof(nonce), f) == sizeof(nonce) && std::fwrite(id, 1, sizeof(id), f) == sizeof(id);
+        if (f) std::fclose(f);
+        if (!ok) throw std::runtime_error("cannot write '" + tmp + "'");
         if (std::rename(tmp.c_str(), idFile.c_str()) != 0) throw std::runtime_error("cannot publish '" + idFile + "'");
     } else {
         bool have = false;
         for (int tries = 0; tries < 6000 && !have; tries++) { // up to 60 s for rank 0 to come up
             FILE* f = std::fopen(idFile.c_str(), "rb");
             if (f) {
-                have = std::fread(id, 1, sizeof(id), f) == sizeof(id);
+                unsigned long long seen = 0;
+                have = std::fread(&seen, 1, sizeof(seen), f) == sizeof(seen) && seen == nonce && std::fread(id, 1, sizeof(id), f) == sizeof(id);
                 std::fclose(f);
             }
             if (!have) std::this_thread::sleep_for(std::chrono::milliseconds(10));
         }
-        if (!have) throw std::runtime_error("rank " + std::to_string(rankIn) + ": no communicator id in '" + idFile + "'");
+        if (!have) throw std::runtime_error("rank " + std::to_string(rankIn) + ": no communicator id of this launch in '" + idFile + "'");
     }
     check(crt_comm_init(ctx, rankIn, nRanksIn, id), "crt_comm_init");
     rank = rankIn;

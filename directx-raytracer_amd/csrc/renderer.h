@@ -47,7 +47,7 @@ public:
     // N GPUs, one process each (no reference counterpart): join the RCCL communicator of an N-rank run.  Rank 0 creates the
     // 128-byte id and publishes it as `idFile` (written under a temporary name, then renamed); the other ranks wait for the
     // file.  Afterwards renderFrame() renders this rank's tiles, gathers and de-interleaves: every rank holds the frame.
-    void joinRanks(uint32_t rank, uint32_t nRanks, const std::string& idFile);
+    void joinRanks(uint32_t rank, uint32_t nRanks, const std::string& idFile, unsigned long long nonce = 0);
     uint32_t getRank() const { return rank; }
     uint32_t getRankCount() const { return nRanks; }
 

@@ -81,3 +81,14 @@ def test_product_does_not_reference_the_oracle():
                 assert "libcrt_oracle" not in text and "crt_oracle.h" not in text, f
     out = os.popen("ldd %s" % os.path.join(pkg_dir, "libcrt_hip.so")).read()
     assert "oracle" not in out
+
+
+def test_rank_launcher_reports_the_first_failed_rank_and_returns(pkg, golden_dir):
+    """crt_render --ranks N (the C++-only N-GPU launcher): when a rank fails -- here every rank does, there is no GPU -- the parent
+    names the rank that went first, stops the others and returns non-zero instead of waiting for peers stuck in a collective."""
+    import subprocess
+    exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "crt_render")
+    assert os.path.exists(exe), "crt_render not built"
+    out = subprocess.run([exe, os.path.join(golden_dir, "dragon.crtscene"), "--ranks", "3", "--frames", "1"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 1
+    assert "stopping the other ranks" in out.stderr and "rank" in out.stderr

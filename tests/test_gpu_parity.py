@@ -224,22 +224,42 @@ def test_c3_tiled_over_2_4_8_ranks_vs_oracle(pkg, oracle, scenes, renderer):
 
 def test_rccl_gather_path_of_bench_in_a_fresh_process():
     """The real N>1 code path of bench.py -- RCCL communicator init, tile staging, ONE all-gather per launch, de-interleave --
-    in a fresh child process with world size 1 (all this box has); the child compares the gathered frame with the oracle's
-    and exits non-zero on any difference.  Both pipelining policies run (1 launch in flight, and 4 in flight)."""
+    in a fresh child process with world size 1 (all this box has) and NO launcher environment (no WORLD_SIZE / RANK / MASTER_*
+    preset: bench.py finds its own rendezvous, as when the driver calls `python bench.py --gpus N`); the child compares the
+    gathered frame with the oracle's and exits non-zero on any difference.  Both pipelining policies run (1 launch in flight,
+    and 4 in flight)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
-               HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--force-dist", "--steps", "6", "--warmup", "2",
-                          "--check-dist-frame"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "6", "--warmup", "2",
+                          "--no-cpu-baseline", "--check-dist-frame"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["frame_matches_oracle"] is True
     assert line["config"]["launches_in_flight"] == 1 and line["config"]["frames_per_launch"] == 1
     assert line["pipelined"]["launches_in_flight"] == 4 and line["pipelined"]["value"] > 0
+    assert line["rank0_render_kernel_ms"] > 0 and line["rank0_gather_untile_us"] > 0
     assert "all-gather" in line["config"]["parallelism"] or line["n_gpus"] == 1
+
+
+def test_bench_c5_config_runs_and_matches_the_oracle_on_sampled_rows():
+    """`bench.py --config c5` (BASELINE.json configs[4]: 5M triangles, 3840x2160, 4 spp, 3 bounces) through the N>1 path with
+    the one rank a box has: the tile-partitioned path-traced frame equals the oracle's on the rows the CPU sample covers."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--config", "c5", "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1",
+                          "--no-extras", "--no-cpu-baseline", "--check-dist-frame", "--spinup-ms", "0"], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["frame_matches_oracle"] is True and line["frame_rows_checked"] >= 8
+    assert "4999124 triangles, 3840x2160" in line["config"]["workload"] and line["config"]["rays_per_frame"] > 4 * 3840 * 2160
 
 
 def test_obj_scene_renders_like_the_oracle(pkg, oracle, scenes, renderer, tmp_path):

@@ -45,3 +45,20 @@ def test_world_size_2_gloo_gather():
                          env=dict(os.environ, OMP_NUM_THREADS="2"))
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
     assert "TILE_GATHER_OK" in out.stdout
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` with no launcher environment (how the driver calls it): the parent must start two ranks with
+    torch.distributed.run as a child process before anything touches a GPU, and relay the rank-0 line and the exit code.
+    Here (no GPU) the ranks only rendezvous -- over gloo -- add up their ranks and leave."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rendezvous-only", "--backend", "gloo"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(env, OMP_NUM_THREADS="2"))
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line == {"rendezvous_ok": True, "n_gpus": 2, "backend": "gloo"}
+    # a rank that fails takes the whole launch down with a non-zero exit code
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(env, OMP_NUM_THREADS="2"))
+    assert bad.returncode != 0  # (no GPU here: "bench.py needs an MI355X")
