@@ -68,6 +68,7 @@ struct crt_ctx {
     double buildMs = 0.0;       // wall time of the last crt_upload_scene (build + upload)
     double buildDeviceMs = 0.0; // of which GPU kernels (gpu_build only)
     uint32_t sceneSerial = 0;
+    float sceneLo[3] = { 0.f, 0.f, 0.f }, sceneHi[3] = { 0.f, 0.f, 0.f }; // box of the tree's root: where split rays are cut into segments
 
     float pos[3] = { 0.f, 0.f, 0.f };
     float rot[9] = { 1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f };
@@ -217,6 +218,8 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     crt::copyBytes(p.pos, c->pos, sizeof(p.pos));
     crt::copyBytes(p.rot, c->rot, sizeof(p.rot));
     crt::copyBytes(p.miss, c->miss, sizeof(p.miss));
+    crt::copyBytes(p.scene_lo, c->sceneLo, sizeof(p.scene_lo));
+    crt::copyBytes(p.scene_hi, c->sceneHi, sizeof(p.scene_hi));
     p.mode = c->mode;
     p.spp = c->pathSpp;
     p.max_bounces = c->pathBounces;
@@ -273,7 +276,9 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         p.spill_stride = deepest > p.stack_entries ? deepest - p.stack_entries : 1u;
         // (mode 200: one slice per resident workgroup of the persistent kernel)
         if (p.mode >= 200u) p.path_tile = c->tunePathTile ? c->tunePathTile : 8u;
-        const size_t groups = p.mode >= 200u ? static_cast<size_t>(crt::pathGridSize(p)) : static_cast<size_t>(crt::renderUnitCount(p)) * p.n_batch;
+        // (+ 64 slices for each of the four wavefronts of a split packet)
+        const size_t groups = p.mode >= 200u ? static_cast<size_t>(crt::pathGridSize(p))
+                                             : (static_cast<size_t>(crt::renderUnitCount(p)) + 4u * std::min(c->tuneSplitUnits, crt::renderUnitCount(p))) * p.n_batch;
         const size_t need = groups * 64u * p.spill_stride * sizeof(int);
         if (c->spillBytes[slot] < need) {
             HIP_TRY(c, hipDeviceSynchronize());
@@ -642,6 +647,15 @@ int crt_upload_scene(crt_ctx* c, const crt_mesh_view* meshes, uint32_t n_meshes,
     if (n_materials) HIP_TRY(c, hipMemcpy(c->dMats, materials, sizeof(crt_material) * n_materials, hipMemcpyHostToDevice));
     c->nLights = n_lights;
     c->nMats = n_materials;
+    for (int a = 0; a < 3; a++) c->sceneLo[a] = c->sceneHi[a] = 0.0f;
+    if (c->bvh.width == 0 && c->bvh.nNodes4 > 0) { // the root record as it sits in HBM (built here or on the device alike)
+        crt_bvh_node4q root;
+        HIP_TRY(c, hipMemcpy(&root, c->dNodes, sizeof(root), hipMemcpyDeviceToHost));
+        for (int a = 0; a < 3; a++) {
+            c->sceneLo[a] = root.lo[a];
+            c->sceneHi[a] = crt::decodePlane(255u, root.s[a], root.lo[a]);
+        }
+    }
     c->buildMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tb0).count();
     c->haveScene = true;
     c->sceneSerial++;

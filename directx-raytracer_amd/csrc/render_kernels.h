@@ -43,7 +43,8 @@ struct RenderParams {
     uint32_t debug_skip_units;   // diagnostics: with unit_order, the first N work units are not rendered
     uint32_t boost_units;        // with unit_order: the first boost_units (most expensive) work units run at raised priority
     uint32_t split_units;        // with unit_order: the first split_units work units are rendered by FOUR wavefronts, one per 4x4
-                                 // quarter of the 8x8 packet (16 lanes each): the frame's critical path is its slowest packets
+                                 // quarter of the 8x8 packet, every ray by four lanes (four segments of its way through the scene)
+    float scene_lo[3], scene_hi[3]; // the scene's box (root of the tree): where a split ray's segments are cut
     uint32_t xcd_group;          // consecutive tiles of the list handed to one XCD before moving to the next (1..16, power of 2)
     // outputs (device pointers, nullable except rgba8)
     uint32_t* rgba8;

@@ -394,8 +394,13 @@ def test_scheduling_knobs_never_change_results(pkg, oracle, scenes, dragon, rend
                     for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
                         np.testing.assert_array_equal(got[k], ref[k], err_msg="%s=%d frame %d %s" % (name, v, frame, k))
                     assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True)
-                    assert got["stats"]["nodes_visited"] == ref["stats"]["nodes_visited"]
-                    assert got["stats"]["tris_tested"] == ref["stats"]["tris_tested"]
+                    assert got["stats"]["rays_primary"] == ref["stats"]["rays_primary"] and got["stats"]["rays_shadow"] == ref["stats"]["rays_shadow"]
+                    if name == "split_units" and v > 0:
+                        # a split packet's rays are traced as four segments that each descend from the root: same hits, more fetches
+                        assert got["stats"]["nodes_visited"] >= ref["stats"]["nodes_visited"]
+                    else:
+                        assert got["stats"]["nodes_visited"] == ref["stats"]["nodes_visited"]
+                        assert got["stats"]["tris_tested"] == ref["stats"]["tris_tested"]
             renderer.set_option(name, defaults[name])
         with pytest.raises(pkg.CrtError):
             renderer.set_option("no_such_option", 1)
@@ -405,6 +410,50 @@ def test_scheduling_knobs_never_change_results(pkg, oracle, scenes, dragon, rend
         renderer.set_counting(False)
         for name, v in defaults.items():
             renderer.set_option(name, v)
+
+
+def test_split_packets_render_the_same_frame(pkg, oracle, scenes, renderer):
+    """Option split_units: the most expensive 8x8 packets are rendered by four wavefronts, every ray by four lanes that each trace
+    a quarter of its way through the scene (closest hit = first segment with a hit; a shadow ray is occluded if any segment is).
+    C3 scene, whole frame and an 8-rank tile share, primary rays only and with shadow rays (plain and Phong): hit ids, t and
+    colours are the oracle's bit for bit."""
+    import torch
+    sc = scenes.heightfield(n_lights=1)
+    cam = sc["camera"]
+    renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+    renderer.set_camera(cam["position"], cam["matrix"])
+    w, h = 1920, 1080
+    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    try:
+        for mode, phong in ((3, 0), (100, 0), (100, 300)):
+            renderer.change_shading_mode(mode)
+            renderer.set_option("phong_ks", phong)
+            oracle.set_phong(phong, 32)
+            ref = O.render(cam["position"], cam["matrix"], mode, w, h)
+            for split in (300, 4096):
+                renderer.set_option("split_units", split)
+                for frame in range(10):  # the launch order (and with it the split) comes from an earlier frame's costs
+                    got = renderer.render_frame(w, h)
+                for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
+                    np.testing.assert_array_equal(got[k], ref[k], err_msg="mode %d phong %d split %d %s" % (mode, phong, split, k))
+                assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True)
+            # an 8-rank share (what the split is for: its launch lasts as long as its slowest packet)
+            n = 8
+            slots = pkg.tile_slots(w, h, n)
+            gathered = torch.zeros(n * slots * 256, dtype=torch.int32, device="cuda")
+            frame_t = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            for rep in range(10):
+                for rank in range(n):
+                    renderer.render_tiles_device(w, h, rank, n, gathered.data_ptr() + rank * slots * 1024)
+            renderer.untile_device(w, h, n, gathered.data_ptr(), frame_t.data_ptr())
+            renderer.synchronize()
+            np.testing.assert_array_equal(frame_t.cpu().numpy().view(np.uint32).reshape(h, w), ref["rgba8"].view(np.uint32).reshape(h, w))
+    finally:
+        renderer.set_option("split_units", 0)
+        renderer.set_option("phong_ks", 0)
+        oracle.set_phong(0, 32)
+        renderer.change_shading_mode(0)
 
 
 def _compare_path(pkg, oracle, renderer, sc, w, h, spp, bounces, seed, miss=(0.0, 0.0, 0.0)):

@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Split packets (option split_units): frame identical to the unsplit one, and what a lone launch of an N-rank share costs.
+tools/split_probe.py [--mode 100]"""
+
+
+def main():
+    import argparse, importlib, os, statistics, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+    import __graft_entry__ as e
+    import numpy as np, torch
+    ap = argparse.ArgumentParser(); ap.add_argument("--mode", type=int, default=100); ap.add_argument("--splits", default="0,64,128,256,512,1024")
+    a = ap.parse_args()
+    pkg = e.load_package(); scenes = importlib.import_module(e.PKG_NAME + ".scenes"); host = importlib.import_module(e.PKG_NAME + ".multigpu")
+    if os.environ.get("CRT_LIB"): pkg.LIB_PATH = os.path.abspath(os.environ["CRT_LIB"])
+    sc = scenes.heightfield(n_lights=1)
+    r = pkg.Renderer(0); r.upload(sc["meshes"], sc["lights"], sc["materials"]); r.set_camera(sc["camera"]["position"], sc["camera"]["matrix"]); r.change_shading_mode(a.mode)
+    W, H = 1920, 1080
+    ref = None
+    for N in (1, 8):
+        share = host.rank_share(W, H, 0, N)
+        staging = torch.zeros(share["slots"] * 256, dtype=torch.int32, device="cuda")
+        torch.cuda.synchronize()
+        for split in [int(v) for v in a.splits.split(",")]:
+            r.set_option("split_units", split)
+            for _ in range(14): r.render_tiles_device(W, H, 0, N, staging.data_ptr(), stats=True)
+            ms = statistics.median([r.render_tiles_device(W, H, 0, N, staging.data_ptr(), stats=True)["kernel_ms"] for _ in range(25)])
+            img = staging.cpu().numpy().copy()
+            if split == 0: ref = img
+            print("N=%d split_units=%4d: one launch alone %.1f us   staging %s" % (N, split, ms * 1e3, "identical" if np.array_equal(img, ref) else "DIFFERS (%d)" % int((img != ref).sum())), flush=True)
+    r.set_option("split_units", 0)
+
+
+if __name__ == "__main__":
+    main()
