@@ -1,14 +1,15 @@
 // GPU BVH build: stands in for BuildRaytracingAccelerationStructure, which the reference
 // runs on the GPU at init (R/DXRTRenderer.cpp:548-806).  LBVH: 30-bit Morton codes of the quantised box centroids,
-// radix sort, Karras 2012 hierarchy, bottom-up exact box fitting, ranges of <= 4 triangles collapsed to leaves.
+// radix sort, Karras 2012 hierarchy, bottom-up exact box fitting, ranges of <= 2 triangles collapsed to leaves, then --
+// still on the device -- the collapse to the 4-wide tree (level by level, bvh_wide.h wideSlots) and its quantisation.
 // Specification = oracle/crt_oracle.c build_lbvh(); the two produce byte-identical trees (tests/test_gpu_parity.py).
 // The meshes go up as they are (vertices, indices, normals, uvs: 18 MB for 1M triangles instead of 130 MB of flattened
-// records); triangle boxes and the leaf-ordered triangle / shading / uv records are produced on the device and STAY there
-// (the context adopts the buffers); only the binary nodes come back, for the host routine that collapses them to the 4-wide
-// tree and quantises it, shared with the SAH path.
+// records); triangle boxes, the leaf-ordered triangle / shading / uv records, the binary nodes, the wide nodes and their
+// quantised form are produced on the device and STAY there (the context adopts the buffers; crt_bvh_export* read them back
+// on demand).  Nothing but a few counters comes back to the host.
 // Cubic Morton cells and leaves of at most 2 triangles (per-axis scaling and the SAH builder's 4-triangle leaves measured +36 %
 // node fetches and +94 % triangle tests against the SAH tree on the 1M-triangle frame; now +18 % / -13 %).  It is the fast
-// option (option "gpu_build": 16 ms against 350 ms at 1M triangles), not the default.
+// option (option "gpu_build": 8.7 ms against 360 ms at 1M triangles), not the default.
 #include "bvh_build.h"
 #include "bvh_wide.h"
 
@@ -571,9 +572,17 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
     if (timing) { GPU_TRY(hipStreamSynchronize(stream)); }
     lap("alloc + H2D meshes");
 
-    hipEvent_t e0, e1;
-    GPU_TRY(hipEventCreate(&e0));
-    GPU_TRY(hipEventCreate(&e1));
+    struct Events { // destroyed on every way out, exceptions included
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        ~Events()
+        {
+            if (e0) (void)hipEventDestroy(e0);
+            if (e1) (void)hipEventDestroy(e1);
+        }
+    } ev;
+    GPU_TRY(hipEventCreate(&ev.e0));
+    GPU_TRY(hipEventCreate(&ev.e1));
+    hipEvent_t e0 = ev.e0, e1 = ev.e1;
     GPU_TRY(hipEventRecord(e0, stream));
     const dim3 blk(256), grdN((n + 255) / 256), grdI((nInternal + 255) / 256);
     hipLaunchKernelGGL(triBoxKernel, grdN, blk, 0, stream, dTable.as<MeshEntry>(), n_meshes, dXyz.as<float>(), dIdx.as<uint32_t>(), n, dBox.as<Box6>(),
@@ -583,25 +592,25 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
     // keys = Morton code << 32 | ordinal, written in ordinal order: a stable sort on the four bytes of the high dword orders the full keys;
     // four passes ping-pong dKeys -> dKeysIn -> ... and end in dKeys
     hipLaunchKernelGGL(mortonKernel, grdN, blk, 0, stream, dCent.as<float>(), n, dBounds.as<int>(), dKeys.as<unsigned long long>());
-    if (gpusort::sortKeysHigh(dKeys.as<unsigned long long>(), dKeysIn.as<unsigned long long>(), n, 4, dSortCounts.as<uint32_t>(), stream) != dKeys.as<unsigned long long>())
-        throw std::logic_error("sorted keys expected in the first buffer");
+    GPU_TRY(hipGetLastError()); // triBox / bounds / Morton launches
+    hipError_t sortStatus = hipSuccess;
+    unsigned long long* sorted = gpusort::sortKeysHigh(dKeys.as<unsigned long long>(), dKeysIn.as<unsigned long long>(), n, 4, dSortCounts.as<uint32_t>(), stream, &sortStatus);
+    GPU_TRY(sortStatus);
+    if (sorted != dKeys.as<unsigned long long>()) throw std::logic_error("sorted keys expected in the first buffer");
     hipLaunchKernelGGL(hierarchyKernel, grdI, blk, 0, stream, dKeys.as<unsigned long long>(), n, dK.as<KNode>(), dParI.as<int>(), dParL.as<int>());
     GPU_TRY(hipMemsetAsync(dFlags.p, 0, sizeof(unsigned int) * nInternal, stream));
     hipLaunchKernelGGL(fitKernel, grdN, blk, 0, stream, dK.as<KNode>(), dBox.as<Box6>(), dKeys.as<unsigned long long>(), n, dParI.as<int>(),
                        dParL.as<int>(), dNodeBox.as<Box6>(), dFlags.as<unsigned int>());
     hipLaunchKernelGGL(keptKernel, grdI, blk, 0, stream, dK.as<KNode>(), nInternal, dKept.as<uint32_t>());
-    gpusort::exclusiveSum(dKept.as<uint32_t>(), dRank.as<uint32_t>(), nInternal, dScanSums.as<uint32_t>(), stream);
+    GPU_TRY(hipGetLastError()); // hierarchy / fit / kept launches
+    GPU_TRY(gpusort::exclusiveSum(dKept.as<uint32_t>(), dRank.as<uint32_t>(), nInternal, dScanSums.as<uint32_t>(), stream));
     uint32_t lastKept = 0, lastRank = 0;
     int bad = 0;
     GPU_TRY(hipMemcpyAsync(&lastKept, dKept.as<uint32_t>() + (nInternal - 1), 4, hipMemcpyDeviceToHost, stream));
     GPU_TRY(hipMemcpyAsync(&lastRank, dRank.as<uint32_t>() + (nInternal - 1), 4, hipMemcpyDeviceToHost, stream));
     GPU_TRY(hipMemcpyAsync(&bad, dBad.p, sizeof(int), hipMemcpyDeviceToHost, stream));
     GPU_TRY(hipStreamSynchronize(stream));
-    if (bad) {
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        throw std::runtime_error("triangle index out of range");
-    }
+    if (bad) throw std::runtime_error("triangle index out of range");
     const uint32_t nKept = lastKept + lastRank;
     DevBuf dNodes(sizeof(crt_bvh_node) * nKept);
     hipLaunchKernelGGL(emitKernel, grdI, blk, 0, stream, dK.as<KNode>(), dKept.as<uint32_t>(), dRank.as<uint32_t>(), dNodeBox.as<Box6>(), dBox.as<Box6>(),
@@ -629,6 +638,7 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
             GPU_TRY(hipMemsetAsync(dScalars.p, 0, sizeof(uint32_t), stream));
             hipLaunchKernelGGL(wideExpandKernel, dim3((count + 255) / 256), blk, 0, stream, dNodes.as<crt_bvh_node>(), cur, count, base, base + count,
                                dTmp.as<WideTmp>(), nxt, dScalars.as<uint32_t>(), dScalars.as<uint32_t>() + 1);
+            GPU_TRY(hipGetLastError());
             uint32_t nextCount = 0;
             GPU_TRY(hipMemcpyAsync(&nextCount, dScalars.p, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
             GPU_TRY(hipStreamSynchronize(stream));
@@ -654,8 +664,6 @@ void buildBvhGpu(const crt_mesh_view* meshes, uint32_t n_meshes, Bvh& out, ihipS
     GPU_TRY(hipStreamSynchronize(stream));
     float ms = 0.f;
     GPU_TRY(hipEventElapsedTime(&ms, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
     if (device_ms) *device_ms = ms;
     lap("device collapse + quantise");
     out.maxDepth = maxDepth;

@@ -1133,16 +1133,17 @@ struct RcclApi {
     std::string error;
 };
 
-RcclApi& rccl()
+// loaded once, whichever thread asks first (the initialiser of a function-local static runs exactly once; later callers wait for it)
+RcclApi loadRccl()
 {
-    static RcclApi api;
-    if (api.handle || !api.error.empty()) return api;
+    RcclApi api;
     for (const char* name : { "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so" }) {
         api.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (api.handle) break;
     }
     if (!api.handle) {
-        api.error = std::string("cannot load RCCL (librccl.so.1): ") + dlerror();
+        const char* why = dlerror(); // may be NULL
+        api.error = std::string("cannot load RCCL (librccl.so.1): ") + (why ? why : "unknown dlopen error");
         return api;
     }
     api.getUniqueId = reinterpret_cast<decltype(api.getUniqueId)>(dlsym(api.handle, "ncclGetUniqueId"));
@@ -1154,6 +1155,12 @@ RcclApi& rccl()
         api.error = "RCCL library lacks an expected entry point";
         api.handle = nullptr;
     }
+    return api;
+}
+
+RcclApi& rccl()
+{
+    static RcclApi api = loadRccl();
     return api;
 }
 

@@ -165,12 +165,18 @@ __global__ __launch_bounds__(kThreads) void tileScanKernel(const uint32_t* v, ui
 
 inline size_t scanScratchBytes(uint32_t n) { return sizeof(uint32_t) * tilesFor(n); }
 
-inline void exclusiveSum(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* tileSums, hipStream_t stream)
+// (both host routines return the first launch error of their kernels: hipSuccess, or what hipGetLastError reported right
+// after the launch that failed)
+inline hipError_t exclusiveSum(const uint32_t* in, uint32_t* out, uint32_t n, uint32_t* tileSums, hipStream_t stream)
 {
     const uint32_t nTiles = tilesFor(n);
+    hipError_t e;
     hipLaunchKernelGGL(tileSumKernel, dim3(nTiles), dim3(kThreads), 0, stream, in, n, tileSums);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(scanCountsKernel, dim3(1), dim3(kScanThreads), 0, stream, tileSums, nTiles);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
     hipLaunchKernelGGL(tileScanKernel, dim3(nTiles), dim3(kThreads), 0, stream, in, n, tileSums, out);
+    return hipGetLastError();
 }
 
 // scratch of the sort in uint32: digit counts per tile, then the tile sums of their scan
@@ -179,16 +185,20 @@ inline size_t sortScratchWords(uint32_t n) { return static_cast<size_t>(kDigits)
 // Stable sort of keys[0..n) on bits [32, 32 + 8 * passes): result in `keys` or `alt` (returned).  counts: sortScratchWords(n) uint32.
 // (__shfl of a value held only by the leader, __ballot and the LDS counters all stay inside one wavefront: no barrier
 // between the chunks of a wavefront is needed.)
-inline unsigned long long* sortKeysHigh(unsigned long long* keys, unsigned long long* alt, uint32_t n, int passes, uint32_t* counts, hipStream_t stream)
+inline unsigned long long* sortKeysHigh(unsigned long long* keys, unsigned long long* alt, uint32_t n, int passes, uint32_t* counts, hipStream_t stream,
+                                        hipError_t* status)
 {
     const uint32_t nTiles = tilesFor(n);
     unsigned long long* src = keys;
     unsigned long long* dst = alt;
+    *status = hipSuccess;
     for (int p = 0; p < passes; p++) {
         const uint32_t shift = 32u + 8u * static_cast<uint32_t>(p);
         hipLaunchKernelGGL(histogramKernel, dim3(nTiles), dim3(kThreads), 0, stream, src, n, shift, nTiles, counts);
-        exclusiveSum(counts, counts, kDigits * nTiles, counts + static_cast<size_t>(kDigits) * nTiles, stream); // in place
+        if ((*status = hipGetLastError()) != hipSuccess) return src;
+        if ((*status = exclusiveSum(counts, counts, kDigits * nTiles, counts + static_cast<size_t>(kDigits) * nTiles, stream)) != hipSuccess) return src; // in place
         hipLaunchKernelGGL(scatterKernel, dim3(nTiles), dim3(kThreads), 0, stream, src, dst, n, shift, nTiles, counts);
+        if ((*status = hipGetLastError()) != hipSuccess) return src;
         unsigned long long* x = src; src = dst; dst = x;
     }
     return src;

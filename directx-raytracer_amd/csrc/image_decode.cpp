@@ -1,0 +1,553 @@
+// Bitmap texture decoders: PNG (with its own inflate), BMP, TGA, binary PPM / PGM.  See image_decode.h.
+#include "image_decode.h"
+
+#include <cstdint>
+#include <cstring>
+#include <stdexcept>
+
+namespace crt {
+namespace {
+
+[[noreturn]] void bad(const std::string& what, const char* why) { throw std::runtime_error("texture '" + what + "': " + why); }
+
+constexpr long long kMaxTexels = 1ll << 28;
+
+// ---------------------------------------------------------------------------------------------- inflate (RFC 1951)
+struct BitReader {
+    const unsigned char* p;
+    size_t size, pos = 0;
+    uint32_t hold = 0;
+    int bits = 0;
+    const std::string& what;
+    uint32_t take(int n) // n <= 16
+    {
+        while (bits < n) {
+            if (pos >= size) bad(what, "compressed data ends early");
+            hold |= static_cast<uint32_t>(p[pos++]) << bits;
+            bits += 8;
+        }
+        const uint32_t v = hold & ((1u << n) - 1u);
+        hold >>= n;
+        bits -= n;
+        return v;
+    }
+    void alignToByte()
+    {
+        hold = 0;
+        bits = 0;
+    }
+};
+
+// canonical Huffman code given as code lengths: count[len] codes of each length, symbols ordered by (length, value)
+struct Huffman {
+    uint16_t count[16];
+    uint16_t symbol[288];
+    bool build(const uint8_t* lengths, int n)
+    {
+        std::memset(count, 0, sizeof(count));
+        for (int i = 0; i < n; i++) count[lengths[i]]++;
+        count[0] = 0;
+        int left = 1; // over-subscribed or incomplete sets are rejected (a single code of length 1 is allowed: distance trees)
+        int used = 0;
+        for (int len = 1; len < 16; len++) {
+            left <<= 1;
+            left -= count[len];
+            if (left < 0) return false;
+            used += count[len];
+        }
+        uint16_t offs[16];
+        offs[1] = 0;
+        for (int len = 1; len < 15; len++) offs[len + 1] = static_cast<uint16_t>(offs[len] + count[len]);
+        for (int i = 0; i < n; i++)
+            if (lengths[i]) symbol[offs[lengths[i]]++] = static_cast<uint16_t>(i);
+        return left == 0 || used <= 1;
+    }
+    int decode(BitReader& br) const
+    {
+        int code = 0, first = 0, index = 0;
+        for (int len = 1; len < 16; len++) {
+            code |= static_cast<int>(br.take(1));
+            const int c = count[len];
+            if (code - c < first) return symbol[index + (code - first)];
+            index += c;
+            first += c;
+            first <<= 1;
+            code <<= 1;
+        }
+        return -1;
+    }
+};
+
+const uint16_t kLenBase[29] = { 3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258 };
+const uint8_t kLenExtra[29] = { 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0 };
+const uint16_t kDistBase[30] = { 1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577 };
+const uint8_t kDistExtra[30] = { 0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13 };
+
+void inflateBlock(BitReader& br, const Huffman& lit, const Huffman& dist, std::vector<unsigned char>& out, size_t limit)
+{
+    for (;;) {
+        const int sym = lit.decode(br);
+        if (sym < 0) bad(br.what, "bad Huffman code");
+        if (sym < 256) {
+            if (out.size() >= limit) bad(br.what, "decompressed data larger than the image");
+            out.push_back(static_cast<unsigned char>(sym));
+        } else if (sym == 256) {
+            return;
+        } else {
+            if (sym > 285) bad(br.what, "bad length symbol");
+            const size_t len = kLenBase[sym - 257] + br.take(kLenExtra[sym - 257]);
+            const int ds = dist.decode(br);
+            if (ds < 0 || ds > 29) bad(br.what, "bad distance symbol");
+            const size_t d = kDistBase[ds] + br.take(kDistExtra[ds]);
+            if (d > out.size()) bad(br.what, "distance reaches before the start of the data");
+            if (out.size() + len > limit) bad(br.what, "decompressed data larger than the image");
+            size_t from = out.size() - d;
+            for (size_t i = 0; i < len; i++) out.push_back(out[from++]);
+        }
+    }
+}
+
+} // namespace
+
+std::vector<unsigned char> zlibInflate(const unsigned char* data, size_t size, size_t expectedSize, const std::string& what)
+{
+    if (size < 2 || (data[0] & 0x0F) != 8 || ((data[0] << 8) | data[1]) % 31 != 0 || (data[1] & 0x20)) bad(what, "bad zlib header");
+    BitReader br{ data + 2, size - 2, 0, 0, 0, what };
+    std::vector<unsigned char> out;
+    out.reserve(expectedSize);
+    Huffman lit, dist;
+    for (;;) {
+        const uint32_t last = br.take(1), type = br.take(2);
+        if (type == 0) {
+            br.alignToByte();
+            if (br.pos + 4 > br.size) bad(what, "compressed data ends early");
+            const uint32_t len = br.p[br.pos] | (br.p[br.pos + 1] << 8), nlen = br.p[br.pos + 2] | (br.p[br.pos + 3] << 8);
+            br.pos += 4;
+            if ((len ^ 0xFFFFu) != nlen) bad(what, "bad stored block");
+            if (br.pos + len > br.size) bad(what, "compressed data ends early");
+            if (out.size() + len > expectedSize) bad(what, "decompressed data larger than the image");
+            out.insert(out.end(), br.p + br.pos, br.p + br.pos + len);
+            br.pos += len;
+        } else if (type == 1) {
+            uint8_t l[288], d[30];
+            for (int i = 0; i < 144; i++) l[i] = 8;
+            for (int i = 144; i < 256; i++) l[i] = 9;
+            for (int i = 256; i < 280; i++) l[i] = 7;
+            for (int i = 280; i < 288; i++) l[i] = 8;
+            for (int i = 0; i < 30; i++) d[i] = 5;
+            lit.build(l, 288);
+            dist.build(d, 30);
+            inflateBlock(br, lit, dist, out, expectedSize);
+        } else if (type == 2) {
+            const int nlen = static_cast<int>(br.take(5)) + 257, ndist = static_cast<int>(br.take(5)) + 1, ncode = static_cast<int>(br.take(4)) + 4;
+            if (nlen > 286 || ndist > 30) bad(what, "bad dynamic block header");
+            static const uint8_t order[19] = { 16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15 };
+            uint8_t lengths[320];
+            std::memset(lengths, 0, sizeof(lengths));
+            for (int i = 0; i < ncode; i++) lengths[order[i]] = static_cast<uint8_t>(br.take(3));
+            Huffman cl;
+            if (!cl.build(lengths, 19)) bad(what, "bad code-length code");
+            uint8_t all[320];
+            int i = 0;
+            while (i < nlen + ndist) {
+                const int sym = cl.decode(br);
+                if (sym < 0) bad(what, "bad Huffman code");
+                if (sym < 16) {
+                    all[i++] = static_cast<uint8_t>(sym);
+                } else {
+                    uint8_t prev = 0;
+                    int rep;
+                    if (sym == 16) {
+                        if (i == 0) bad(what, "repeat without a previous length");
+                        prev = all[i - 1];
+                        rep = 3 + static_cast<int>(br.take(2));
+                    } else if (sym == 17) {
+                        rep = 3 + static_cast<int>(br.take(3));
+                    } else {
+                        rep = 11 + static_cast<int>(br.take(7));
+                    }
+                    if (i + rep > nlen + ndist) bad(what, "too many code lengths");
+                    while (rep--) all[i++] = prev;
+                }
+            }
+            if (all[256] == 0) bad(what, "no end-of-block code");
+            if (!lit.build(all, nlen)) bad(what, "bad literal/length code");
+            if (!dist.build(all + nlen, ndist)) bad(what, "bad distance code");
+            inflateBlock(br, lit, dist, out, expectedSize);
+        } else {
+            bad(what, "bad block type");
+        }
+        if (last) break;
+    }
+    return out;
+}
+
+namespace {
+
+uint32_t be32(const unsigned char* p) { return (static_cast<uint32_t>(p[0]) << 24) | (p[1] << 16) | (p[2] << 8) | p[3]; }
+uint32_t le32(const unsigned char* p) { return (static_cast<uint32_t>(p[3]) << 24) | (p[2] << 16) | (p[1] << 8) | p[0]; }
+uint32_t le16(const unsigned char* p) { return static_cast<uint32_t>(p[1] << 8) | p[0]; }
+
+// ---------------------------------------------------------------------------------------------- PNG
+int paeth(int a, int b, int c)
+{
+    const int p = a + b - c, pa = p > a ? p - a : a - p, pb = p > b ? p - b : b - p, pc = p > c ? p - c : c - p;
+    return (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+}
+
+// undo the scanline filters of one (sub-)image of w x h pixels whose lines are `stride` bytes long, each preceded by its filter byte
+void unfilter(unsigned char* data, size_t w, size_t h, size_t stride, size_t bpp, const std::string& what)
+{
+    (void)w;
+    for (size_t y = 0; y < h; y++) {
+        unsigned char* line = data + y * (stride + 1);
+        const int filter = line[0];
+        unsigned char* cur = line + 1;
+        const unsigned char* up = y ? cur - (stride + 1) : nullptr;
+        if (filter > 4) bad(what, "bad scanline filter");
+        for (size_t i = 0; i < stride; i++) {
+            const int a = i >= bpp ? cur[i - bpp] : 0, b = up ? up[i] : 0, c = (up && i >= bpp) ? up[i - bpp] : 0;
+            int v = cur[i];
+            if (filter == 1) v += a;
+            else if (filter == 2) v += b;
+            else if (filter == 3) v += (a + b) >> 1;
+            else if (filter == 4) v += paeth(a, b, c);
+            cur[i] = static_cast<unsigned char>(v);
+        }
+    }
+}
+
+DecodedImage decodePng(const std::vector<unsigned char>& f, const std::string& what)
+{
+    size_t pos = 8;
+    uint32_t w = 0, h = 0;
+    int depth = 0, color = 0, interlace = 0;
+    bool haveHeader = false, haveTrns = false;
+    unsigned char palette[256 * 4];
+    int paletteLen = 0;
+    for (int i = 0; i < 256; i++) palette[4 * i + 3] = 255;
+    unsigned char trnsKey[3] = { 0, 0, 0 };
+    uint32_t trns16[3] = { 0, 0, 0 };
+    std::vector<unsigned char> idat;
+    for (;;) {
+        if (pos + 8 > f.size()) bad(what, "PNG ends before IEND");
+        const uint32_t len = be32(&f[pos]);
+        const unsigned char* type = &f[pos + 4];
+        if (len > f.size() || pos + 12 + len > f.size()) bad(what, "PNG chunk runs past the end of the file");
+        const unsigned char* d = &f[pos + 8];
+        if (!haveHeader && std::memcmp(type, "IHDR", 4) != 0) bad(what, "PNG does not start with IHDR");
+        if (std::memcmp(type, "IHDR", 4) == 0) {
+            if (len != 13 || haveHeader) bad(what, "bad IHDR");
+            w = be32(d); h = be32(d + 4); depth = d[8]; color = d[9]; interlace = d[12];
+            if (w == 0 || h == 0 || static_cast<long long>(w) * h > kMaxTexels) bad(what, "bad PNG size");
+            if (d[10] != 0 || d[11] != 0 || interlace > 1) bad(what, "unknown PNG compression / filter / interlace method");
+            const bool ok = (color == 0 && (depth == 1 || depth == 2 || depth == 4 || depth == 8 || depth == 16)) ||
+                            ((color == 2 || color == 4 || color == 6) && (depth == 8 || depth == 16)) ||
+                            (color == 3 && (depth == 1 || depth == 2 || depth == 4 || depth == 8));
+            if (!ok) bad(what, "bad PNG colour type / bit depth");
+            haveHeader = true;
+        } else if (std::memcmp(type, "PLTE", 4) == 0) {
+            if (len % 3 != 0 || len > 768) bad(what, "bad PLTE");
+            paletteLen = static_cast<int>(len / 3);
+            for (int i = 0; i < paletteLen; i++) std::memcpy(&palette[4 * i], d + 3 * i, 3);
+        } else if (std::memcmp(type, "tRNS", 4) == 0) {
+            if (!idat.empty()) bad(what, "tRNS after IDAT");
+            if (color == 3) {
+                if (len > static_cast<uint32_t>(paletteLen)) bad(what, "bad tRNS");
+                for (uint32_t i = 0; i < len; i++) palette[4 * i + 3] = d[i];
+                haveTrns = true;
+            } else if (color == 0 || color == 2) {
+                const uint32_t n = color == 0 ? 1u : 3u;
+                if (len != 2 * n) bad(what, "bad tRNS");
+                for (uint32_t i = 0; i < n; i++) {
+                    trns16[i] = static_cast<uint32_t>(d[2 * i] << 8) | d[2 * i + 1];
+                    // samples are compared after their reduction to 8 bits, as stb_image does
+                    static const int scale[9] = { 0, 255, 85, 0, 17, 0, 0, 0, 1 };
+                    trnsKey[i] = depth == 16 ? static_cast<unsigned char>(trns16[i] >> 8) : static_cast<unsigned char>((trns16[i] & 255u) * scale[depth]);
+                }
+                haveTrns = true;
+            } else {
+                bad(what, "tRNS in a PNG with an alpha channel");
+            }
+        } else if (std::memcmp(type, "IDAT", 4) == 0) {
+            if (color == 3 && paletteLen == 0) bad(what, "palette PNG without PLTE");
+            idat.insert(idat.end(), d, d + len);
+        } else if (std::memcmp(type, "IEND", 4) == 0) {
+            break;
+        } else if (!(type[0] & 32)) {
+            bad(what, "unknown critical PNG chunk");
+        }
+        pos += 12 + len;
+    }
+    if (idat.empty()) bad(what, "PNG without image data");
+    const int fileCh = color == 0 ? 1 : color == 2 ? 3 : color == 3 ? 1 : color == 4 ? 2 : 4;
+    const size_t bitsPerPixel = static_cast<size_t>(fileCh) * depth;
+    const size_t bpp = bitsPerPixel >= 8 ? bitsPerPixel / 8 : 1;
+    // the seven Adam7 passes, or the one pass of a plain image
+    static const int x0[7] = { 0, 4, 0, 2, 0, 1, 0 }, y0[7] = { 0, 0, 4, 0, 2, 0, 1 }, dx[7] = { 8, 8, 4, 4, 2, 2, 1 }, dy[7] = { 8, 8, 8, 4, 4, 2, 2 };
+    const int passes = interlace ? 7 : 1;
+    size_t rawSize = 0;
+    size_t pw[7], ph[7];
+    for (int p = 0; p < passes; p++) {
+        pw[p] = interlace ? (w - x0[p] + dx[p] - 1) / dx[p] : w;
+        ph[p] = interlace ? (h - y0[p] + dy[p] - 1) / dy[p] : h;
+        if (interlace && (static_cast<uint32_t>(x0[p]) >= w || static_cast<uint32_t>(y0[p]) >= h)) pw[p] = ph[p] = 0;
+        if (pw[p] && ph[p]) rawSize += ph[p] * (1 + (pw[p] * bitsPerPixel + 7) / 8);
+    }
+    std::vector<unsigned char> raw = zlibInflate(idat.data(), idat.size(), rawSize, what);
+    if (raw.size() != rawSize) bad(what, "PNG image data has the wrong size");
+    // samples as 8-bit values, file channel count
+    std::vector<unsigned char> samples(static_cast<size_t>(w) * h * fileCh);
+    size_t at = 0;
+    for (int p = 0; p < passes; p++) {
+        if (!pw[p] || !ph[p]) continue;
+        const size_t stride = (pw[p] * bitsPerPixel + 7) / 8;
+        unfilter(&raw[at], pw[p], ph[p], stride, bpp, what);
+        for (size_t y = 0; y < ph[p]; y++) {
+            const unsigned char* line = &raw[at + y * (stride + 1) + 1];
+            const size_t oy = interlace ? y0[p] + y * dy[p] : y;
+            for (size_t x = 0; x < pw[p]; x++) {
+                const size_t ox = interlace ? x0[p] + x * dx[p] : x;
+                unsigned char* dst = &samples[(oy * w + ox) * fileCh];
+                if (depth == 8) {
+                    std::memcpy(dst, line + x * fileCh, static_cast<size_t>(fileCh));
+                } else if (depth == 16) {
+                    for (int c = 0; c < fileCh; c++) dst[c] = line[(x * fileCh + c) * 2]; // the high byte
+                } else { // 1, 2, 4 bits, one channel
+                    const size_t bit = x * depth;
+                    const unsigned v = (line[bit >> 3] >> (8 - depth - (bit & 7))) & ((1u << depth) - 1u);
+                    static const int scale[5] = { 0, 255, 85, 0, 17 };
+                    dst[0] = static_cast<unsigned char>(color == 3 ? v : v * scale[depth]);
+                }
+            }
+        }
+        at += ph[p] * (stride + 1);
+    }
+    DecodedImage img;
+    img.width = static_cast<int>(w);
+    img.height = static_cast<int>(h);
+    const size_t n = static_cast<size_t>(w) * h;
+    if (color == 3) {
+        img.channels = haveTrns ? 4 : 3;
+        img.pixels.resize(n * img.channels);
+        for (size_t i = 0; i < n; i++) {
+            const int idx = samples[i];
+            if (idx >= paletteLen) bad(what, "palette index out of range");
+            std::memcpy(&img.pixels[i * img.channels], &palette[4 * idx], static_cast<size_t>(img.channels));
+        }
+    } else if (haveTrns) { // a colour key becomes an alpha channel
+        img.channels = fileCh + 1;
+        img.pixels.resize(n * img.channels);
+        for (size_t i = 0; i < n; i++) {
+            bool key = true;
+            for (int c = 0; c < fileCh; c++) {
+                img.pixels[i * img.channels + c] = samples[i * fileCh + c];
+                key = key && samples[i * fileCh + c] == trnsKey[c];
+            }
+            img.pixels[i * img.channels + fileCh] = key ? 0 : 255;
+        }
+    } else {
+        img.channels = fileCh;
+        img.pixels = std::move(samples);
+    }
+    return img;
+}
+
+// ---------------------------------------------------------------------------------------------- BMP
+DecodedImage decodeBmp(const std::vector<unsigned char>& f, const std::string& what)
+{
+    if (f.size() < 26) bad(what, "BMP file too short");
+    const uint32_t dataOffset = le32(&f[10]), hsz = le32(&f[14]);
+    if (hsz != 12 && hsz != 40 && hsz != 56 && hsz != 108 && hsz != 124) bad(what, "unknown BMP header");
+    if (14 + static_cast<size_t>(hsz) > f.size()) bad(what, "BMP file too short");
+    long long w, h;
+    uint32_t bpp, compression = 0;
+    if (hsz == 12) {
+        w = static_cast<long long>(le16(&f[18]));
+        h = static_cast<long long>(le16(&f[20]));
+        bpp = le16(&f[24]);
+    } else {
+        w = static_cast<int32_t>(le32(&f[18]));
+        h = static_cast<int32_t>(le32(&f[22]));
+        bpp = le16(&f[28]);
+        compression = le32(&f[30]);
+    }
+    const bool flip = h > 0; // rows bottom-up unless the height is negative
+    if (h < 0) h = -h;
+    if (w <= 0 || h <= 0 || w * h > kMaxTexels) bad(what, "bad BMP size");
+    if (compression != 0 && !(compression == 3 && (bpp == 32))) bad(what, "compressed BMP files are not supported");
+    uint32_t mr = 0x00FF0000u, mg = 0x0000FF00u, mb = 0x000000FFu, ma = 0xFF000000u;
+    if (compression == 3) {
+        const size_t maskAt = 14 + 40;
+        if (maskAt + 12 > f.size()) bad(what, "BMP file too short");
+        mr = le32(&f[maskAt]); mg = le32(&f[maskAt + 4]); mb = le32(&f[maskAt + 8]);
+        ma = (hsz >= 56 && maskAt + 16 <= f.size()) ? le32(&f[maskAt + 12]) : 0u;
+        if (mr != 0x00FF0000u || mg != 0x0000FF00u || mb != 0x000000FFu || (ma != 0u && ma != 0xFF000000u)) bad(what, "BMP channel masks other than 8-8-8-8 BGRA are not supported");
+    }
+    DecodedImage img;
+    img.width = static_cast<int>(w);
+    img.height = static_cast<int>(h);
+    const size_t W = static_cast<size_t>(w), H = static_cast<size_t>(h);
+    if (bpp == 8 || bpp == 4 || bpp == 1) {
+        const size_t entry = hsz == 12 ? 3 : 4, palAt = 14 + static_cast<size_t>(hsz);
+        size_t colours = hsz == 12 ? 0 : le32(&f[46]);
+        if (colours == 0 || colours > (1u << bpp)) colours = 1u << bpp;
+        if (palAt + colours * entry > f.size()) bad(what, "BMP palette runs past the end of the file");
+        const size_t stride = ((W * bpp + 31) / 32) * 4;
+        if (dataOffset > f.size() || stride * H > f.size() - dataOffset) bad(what, "BMP pixel data runs past the end of the file");
+        img.channels = 3;
+        img.pixels.resize(W * H * 3);
+        for (size_t y = 0; y < H; y++) {
+            const unsigned char* line = &f[dataOffset + (flip ? H - 1 - y : y) * stride];
+            for (size_t x = 0; x < W; x++) {
+                const size_t bit = x * bpp;
+                const unsigned idx = bpp == 8 ? line[x] : (line[bit >> 3] >> (8 - bpp - (bit & 7))) & ((1u << bpp) - 1u);
+                if (idx >= colours) bad(what, "BMP palette index out of range");
+                const unsigned char* c = &f[palAt + idx * entry];
+                unsigned char* dst = &img.pixels[(y * W + x) * 3];
+                dst[0] = c[2]; dst[1] = c[1]; dst[2] = c[0];
+            }
+        }
+        return img;
+    }
+    if (bpp != 24 && bpp != 32) bad(what, "BMP files of this bit depth are not supported");
+    const size_t bytes = bpp / 8, stride = ((W * bpp + 31) / 32) * 4;
+    if (dataOffset > f.size() || stride * H > f.size() - dataOffset) bad(what, "BMP pixel data runs past the end of the file");
+    img.channels = bpp == 32 ? 4 : 3;
+    img.pixels.resize(W * H * img.channels);
+    bool anyAlpha = false;
+    for (size_t y = 0; y < H; y++) {
+        const unsigned char* line = &f[dataOffset + (flip ? H - 1 - y : y) * stride];
+        for (size_t x = 0; x < W; x++) {
+            const unsigned char* s = line + x * bytes;
+            unsigned char* dst = &img.pixels[(y * W + x) * img.channels];
+            dst[0] = s[2]; dst[1] = s[1]; dst[2] = s[0];
+            if (bpp == 32) {
+                dst[3] = ma ? s[3] : 255;
+                anyAlpha = anyAlpha || s[3] != 0;
+            }
+        }
+    }
+    if (bpp == 32 && ma && !anyAlpha) // an alpha channel that is zero everywhere means "no alpha": opaque (stb_image does the same)
+        for (size_t i = 0; i < W * H; i++) img.pixels[i * 4 + 3] = 255;
+    return img;
+}
+
+// ---------------------------------------------------------------------------------------------- TGA
+DecodedImage decodeTga(const std::vector<unsigned char>& f, const std::string& what)
+{
+    if (f.size() < 18) bad(what, "TGA file too short");
+    const int idLen = f[0], cmapType = f[1], type = f[2], bpp = f[16], descriptor = f[17];
+    const size_t w = le16(&f[12]), h = le16(&f[14]);
+    if (cmapType != 0 || (type != 2 && type != 3 && type != 10 && type != 11)) bad(what, "only true-colour and grey TGA files (types 2, 3, 10, 11) are supported");
+    const bool grey = type == 3 || type == 11, rle = type >= 10;
+    if ((grey && bpp != 8) || (!grey && bpp != 24 && bpp != 32)) bad(what, "TGA files of this bit depth are not supported");
+    if (w == 0 || h == 0) bad(what, "bad TGA size");
+    const size_t bytes = static_cast<size_t>(bpp) / 8, n = w * h;
+    size_t pos = 18 + static_cast<size_t>(idLen);
+    std::vector<unsigned char> raw(n * bytes);
+    if (!rle) {
+        if (pos > f.size() || raw.size() > f.size() - pos) bad(what, "TGA pixel data runs past the end of the file");
+        std::memcpy(raw.data(), &f[pos], raw.size());
+    } else {
+        size_t i = 0;
+        while (i < n) {
+            if (pos >= f.size()) bad(what, "TGA run-length data ends early");
+            const int head = f[pos++];
+            const size_t count = static_cast<size_t>(head & 127) + 1;
+            if (i + count > n) bad(what, "TGA run crosses the end of the image");
+            if (head & 128) {
+                if (pos + bytes > f.size()) bad(what, "TGA run-length data ends early");
+                for (size_t k = 0; k < count; k++) std::memcpy(&raw[(i + k) * bytes], &f[pos], bytes);
+                pos += bytes;
+            } else {
+                if (pos + count * bytes > f.size()) bad(what, "TGA run-length data ends early");
+                std::memcpy(&raw[i * bytes], &f[pos], count * bytes);
+                pos += count * bytes;
+            }
+            i += count;
+        }
+    }
+    DecodedImage img;
+    img.width = static_cast<int>(w);
+    img.height = static_cast<int>(h);
+    img.channels = static_cast<int>(bytes);
+    img.pixels.resize(n * bytes);
+    const bool topDown = (descriptor >> 5) & 1, rightLeft = (descriptor >> 4) & 1;
+    for (size_t y = 0; y < h; y++) {
+        const size_t sy = topDown ? y : h - 1 - y;
+        for (size_t x = 0; x < w; x++) {
+            const unsigned char* s = &raw[(sy * w + (rightLeft ? w - 1 - x : x)) * bytes];
+            unsigned char* dst = &img.pixels[(y * w + x) * bytes];
+            if (grey) dst[0] = s[0];
+            else {
+                dst[0] = s[2]; dst[1] = s[1]; dst[2] = s[0];
+                if (bytes == 4) dst[3] = s[3];
+            }
+        }
+    }
+    return img;
+}
+
+// ---------------------------------------------------------------------------------------------- binary PPM / PGM
+DecodedImage decodePnm(const std::vector<unsigned char>& f, const std::string& what)
+{
+    size_t pos = 2;
+    auto nextInt = [&]() -> long long {
+        for (;;) { // whitespace and # comments
+            if (pos >= f.size()) bad(what, "bad PNM header");
+            const int c = f[pos];
+            if (c == '#') {
+                while (pos < f.size() && f[pos] != '\n') pos++;
+            } else if (c == ' ' || c == '\n' || c == '\r' || c == '\t') {
+                pos++;
+            } else {
+                break;
+            }
+        }
+        long long v = 0;
+        int digits = 0;
+        while (pos < f.size() && f[pos] >= '0' && f[pos] <= '9' && digits < 10) {
+            v = v * 10 + (f[pos++] - '0');
+            digits++;
+        }
+        if (!digits) bad(what, "bad PNM header");
+        return v;
+    };
+    const long long w = nextInt(), h = nextInt(), maxv = nextInt();
+    pos++; // the single whitespace byte after maxval
+    if (w <= 0 || h <= 0 || maxv != 255 || w * h > kMaxTexels) bad(what, "bad PNM header");
+    DecodedImage img;
+    img.width = static_cast<int>(w);
+    img.height = static_cast<int>(h);
+    img.channels = f[1] == '6' ? 3 : 1;
+    const size_t bytes = static_cast<size_t>(w) * h * img.channels;
+    if (pos > f.size() || bytes > f.size() - pos) bad(what, "truncated");
+    img.pixels.assign(f.begin() + static_cast<long>(pos), f.begin() + static_cast<long>(pos + bytes));
+    return img;
+}
+
+bool endsWith(const std::string& s, const char* suffix)
+{
+    const size_t n = std::strlen(suffix);
+    if (s.size() < n) return false;
+    for (size_t i = 0; i < n; i++) {
+        const char a = s[s.size() - n + i], b = suffix[i];
+        if ((a >= 'A' && a <= 'Z' ? a + 32 : a) != b) return false;
+    }
+    return true;
+}
+
+} // namespace
+
+DecodedImage decodeImage(const std::vector<unsigned char>& f, const std::string& what)
+{
+    static const unsigned char pngMagic[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    if (f.size() >= 8 && std::memcmp(f.data(), pngMagic, 8) == 0) return decodePng(f, what);
+    if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') return decodeBmp(f, what);
+    if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) return decodePnm(f, what);
+    if (endsWith(what, ".tga")) return decodeTga(f, what); // TGA has no magic number: by its name
+    bad(what, "not a PNG, BMP, TGA or binary PPM / PGM file (JPEG, GIF, PSD, HDR and PIC, which the reference's stb_image also reads, are not supported)");
+}
+
+} // namespace crt

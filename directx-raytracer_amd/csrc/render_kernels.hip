@@ -5,7 +5,7 @@
 //
 // Mapping: one 64-thread workgroup = one wavefront = one 8x8-pixel ray packet (the work unit); four units form the
 // 16x16 macro tile that is the unit of multi-GPU ownership.  Every lane owns one ray and a private traversal stack
-// in LDS (entry e of lane l at dword e*64+l: conflict free, 24 entries = 6 KB per wavefront; deeper entries spill
+// in LDS (entry e of lane l at dword e*64+l: conflict free, 16 entries = 4 KB per wavefront; deeper entries spill
 // to a global arena).  The tree is 4-wide; a node is fetched per lane with dwordx4 loads, or once per wavefront
 // through the scalar cache when all lanes stand on the same node; triangles are 48-byte records.  Units are
 // launched most-expensive-first from the cost the previous frame measured.

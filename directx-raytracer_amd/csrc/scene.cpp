@@ -1,6 +1,9 @@
 // Host scene layer: math, mesh, camera.  Behaviour follows the reference classes cited in scene.h and is
 // pinned by tests/golden/dragon_scene_layer.json (values produced by the reference's own sources).
 #include "scene.h"
+#include "image_decode.h"
+
+#include <iterator>
 
 #include <algorithm>
 #include <cmath>
@@ -213,32 +216,27 @@ void TextureDesc::loadBitmap(const std::string& sceneDir)
     std::ifstream in(filePath, std::ios::binary);
     if (!in && !sceneDir.empty()) in.open(sceneDir + "/" + filePath, std::ios::binary);
     if (!in) throw std::runtime_error("cannot open texture file '" + filePath + "'");
-    std::string magic;
-    in >> magic;
-    if (magic != "P6" && magic != "P5") throw std::runtime_error("texture '" + filePath + "': only binary PPM/PGM (P6/P5) bitmaps are supported");
-    auto nextInt = [&]() {
-        for (;;) { // skip whitespace and # comments
-            const int c = in.peek();
-            if (c == '#') { std::string skip; std::getline(in, skip); }
-            else if (c == ' ' || c == '\n' || c == '\r' || c == '\t') in.get();
-            else break;
-        }
-        int v = -1;
-        in >> v;
-        return v;
-    };
-    const int w = nextInt(), h = nextInt(), maxv = nextInt();
-    in.get(); // the single whitespace byte after maxval
-    if (w <= 0 || h <= 0 || maxv != 255 || static_cast<long long>(w) * h > (1ll << 28)) throw std::runtime_error("texture '" + filePath + "': bad PNM header");
-    const int fileCh = magic == "P6" ? 3 : 1;
-    std::vector<unsigned char> raw(static_cast<size_t>(w) * h * fileCh);
-    in.read(reinterpret_cast<char*>(raw.data()), static_cast<std::streamsize>(raw.size()));
-    if (static_cast<size_t>(in.gcount()) != raw.size()) throw std::runtime_error("texture '" + filePath + "': truncated");
-    width = w; height = h; channels = 3;
-    if (fileCh == 3) pixels = std::move(raw);
-    else {
-        pixels.resize(static_cast<size_t>(w) * h * 3);
-        for (size_t i = 0; i < raw.size(); i++) pixels[3 * i] = pixels[3 * i + 1] = pixels[3 * i + 2] = raw[i];
+    std::vector<unsigned char> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+    DecodedImage img = decodeImage(file, filePath); // PNG / BMP / TGA / binary PPM, PGM: image_decode.cpp
+    width = img.width;
+    height = img.height;
+    fileChannels = img.channels;
+    if (img.channels >= 3) {
+        channels = img.channels;
+        pixels = std::move(img.pixels);
+        return;
+    }
+    // Grey (1 channel) and grey + alpha (2): R/CRTTextureBitmap.cpp:24-33 reads buffer[i], buffer[i + 1] and, only when channels > 2,
+    // buffer[i + 2] at i = texel * channels -- so its green is the NEXT byte of the file's layout (the next texel's grey, or this
+    // texel's alpha) and its blue is 0.  Kept as that: the texels are stored as the RGB triple the reference would return (the
+    // read past the last texel, undefined there, gives 0 here), so host, oracle and kernels sample one and the same image.
+    const size_t n = static_cast<size_t>(width) * height;
+    channels = 3;
+    pixels.assign(n * 3, 0);
+    for (size_t i = 0; i < n; i++) {
+        const size_t at = i * static_cast<size_t>(img.channels);
+        pixels[3 * i] = img.pixels[at];
+        pixels[3 * i + 1] = at + 1 < img.pixels.size() ? img.pixels[at + 1] : 0;
     }
 }
 

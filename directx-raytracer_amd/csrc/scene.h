@@ -177,11 +177,12 @@ struct TextureDesc {
     // bitmap texels (rows top to bottom, `channels` bytes per texel), filled by loadBitmap()
     std::vector<unsigned char> pixels;
     int width = 0, height = 0, channels = 0;
+    int fileChannels = 0; // what the file held (1 grey, 2 grey + alpha, 3 RGB, 4 RGBA); `channels` is what `pixels` holds (>= 3)
 
     // CRTTexture::getColor (R/CRTTextureAlbedo.cpp, R/CRTTextureEdges.cpp:9-15, R/CRTTextureChecker.cpp:9-20,
     // R/CRTTextureBitmap.cpp:12-36); pinned by tests/golden/texture_known_answers.json
     Vector getColor(float u = 0.f, float v = 0.f) const;
-    // binary PPM (P6) / PGM (P5, expanded to 3 channels); the reference decodes through stb_image, which is third party.
+    // PNG, BMP, TGA, binary PPM / PGM (image_decode.h); the reference decodes through stb_image, which is third party.
     // Relative paths are tried as given and next to `sceneDir`. Throws std::runtime_error.
     void loadBitmap(const std::string& sceneDir);
     uint32_t typeCode() const; // 0 albedo, 1 edges, 2 checker, 3 bitmap (crt_texture.type)

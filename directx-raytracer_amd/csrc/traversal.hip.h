@@ -151,7 +151,7 @@ __device__ __forceinline__ bool triTest(const Ray& r, const float4 a, const floa
 }
 
 // Per-lane traversal stack.  The first `cap` entries live in LDS (entry e of lane l at dword e*64+l: conflict free); cap
-// is chosen so that 26 wavefronts per CU fit its 160 KB (24 entries = 6 KB per wavefront).  No ray of the test scenes ever holds more than 15
+// is chosen so that the 28 wavefronts per CU the register budget allows fit its 160 KB (16 entries = 4 KB per wavefront).  No ray of the test scenes ever holds more than 15
 // entries while the trees are 24..26 deep, but the builder allows depth 32, so deeper entries spill to a per-lane slice
 // of a global arena that is never touched otherwise: any tree stays correct with the small LDS footprint.
 struct Stack {

@@ -112,7 +112,7 @@ typedef struct crt_frame_stats {
     double total_ms;         /* wall time of the call (includes D2H copies when host outputs are requested) */
     uint64_t rays_primary;   /* closest-hit rays: pixels rendered by this call (x spp + bounce rays in mode 200, exact when counting) */
     uint64_t rays_shadow;    /* counted only when counting is enabled, else 0 */
-    uint64_t nodes_visited;  /* idem: 128-byte wide-node records fetched, summed over all rays */
+    uint64_t nodes_visited;  /* idem: 64-byte quantised wide-node records fetched, summed over all rays */
     uint64_t tris_tested;    /* idem: 48-byte triangle records fetched */
 } crt_frame_stats;
 
@@ -218,7 +218,9 @@ int crt_render_frame_distributed(crt_ctx* ctx, uint32_t width, uint32_t height, 
  * change): "inner_min" 1..65 wave scheduling of the traversal loop, "xcd_group", "adaptive_order" (launch the most expensive 8x8
  * packets of the previous frame first: 0 never, 1 always, 2 = default: only for a frame issued on the same stream as the frame
  * before, where frames run one after another), "remeasure_every" (a moving camera re-measures packet costs every n-th use of a scratch slot; default 1), "boost_units",
- * "split_units" (with a launch order: the n most expensive 8x8 packets are rendered as four 4x4 quarters; default 0 = off),
+ * "split_units" (with a launch order: the n most expensive 8x8 packets are rendered by four wavefronts, one per 4x4 quarter, every
+ * ray by four lanes that each trace a quarter of its way through the scene -- same frame, shorter critical path: the lone launch of
+ * an 8-rank tile share of primary rays goes from 144 to 104 us; fetch counters of split packets grow; default 0 = off),
  * "xcd_affine_order" 0/1 (with a launch order: the frame is cut into eight regions of equal cost, one per XCD and its L2, each launched
  * most expensive packet first; default 0 -- primary rays alone gain 5 %, a shaded frame loses 1 %),
  * "path_tile" (mode 200 work split: pixel-tile edge per workgroup, 8 (default, also 0) or 16), "stack_entries" (0 = default 16; deeper entries spill to a
@@ -245,7 +247,8 @@ int crt_bvh_export(const crt_ctx* ctx, crt_bvh_node* nodes, crt_bvh_tri* tris, c
 /* per-triangle texture coordinates in leaf order; *has_uvs = 0 (and nothing copied) when no mesh carried uvs */
 int crt_bvh_export_uv(const crt_ctx* ctx, crt_bvh_uv* uvs, int* has_uvs);
 /* wall time of the last crt_upload_scene (flatten + build + collapse + upload) and, with option "gpu_build" = 1 (LBVH
- * built by HIP kernels instead of the host SAH builder: faster build, slower traversal), the device time of the build kernels */
+ * built by HIP kernels instead of the host SAH builder: 8.7 against 360 ms at 1M triangles, frames over its tree 1.0 .. 1.14 x
+ * the SAH tree's), the device time of the build kernels */
 int crt_build_stats(const crt_ctx* ctx, double* upload_ms, double* device_build_ms);
 /* the wide tree as it sits in HBM: count/depth (any pointer may be NULL), then a copy of the nodes */
 int crt_bvh_info4(const crt_ctx* ctx, uint32_t* n_nodes4, uint32_t* depth4);

@@ -67,8 +67,191 @@ def main():
     subprocess.check_call([os.path.join(HERE, "_ref", "ref_dump"), "--textures", os.path.join(gold, "tex7x5.ppm"), ttmp])
     with open(os.path.join(gold, "texture_known_answers.json"), "w") as f:
         json.dump(json.load(open(ttmp)), f, separators=(",", ":"))
+    # 4) bitmap textures in the other formats the reference's stb_image reads and this repo decodes itself (csrc/image_decode.cpp):
+    #    seeded images written here (PNG: every colour type, 1 / 4 / 8 / 16 bits, all five filters, stored / fixed / dynamic deflate
+    #    blocks, Adam7; BMP: 24 / 32 bit, palette, top-down; TGA: raw / run-length, colour / grey), answers by CRTTextureBitmap
+    answers = {}
+    for name, data in bitmap_fixtures().items():
+        path = os.path.join(gold, name)
+        with open(path, "wb") as f:
+            f.write(data)
+        btmp = os.path.join(HERE, "_ref", "bitmap_ref.json")
+        subprocess.check_call([os.path.join(HERE, "_ref", "ref_dump"), "--bitmap", path, btmp])
+        # stored compactly: [iu, iv, R, G, B] with u = fl(iu * 0.05f + (iu % 3) * 0.003f), v = fl(iv * 0.05f + (iv % 4) * 0.002f) and
+        # the colour the reference returned = fl(R / 255.0f) etc. exactly (checked here)
+        import numpy as np
+        rows = []
+        k = 0
+        for iu in range(21):
+            for iv in range(21):
+                u, v, r, g, b = json.load(open(btmp))[k] if k == 0 else ref[k]
+                if k == 0:
+                    ref = json.load(open(btmp))
+                k += 1
+                f32 = np.float32
+                assert f32(u) == f32(f32(iu) * f32(0.05) + f32(iu % 3) * f32(0.003)) and f32(v) == f32(f32(iv) * f32(0.05) + f32(iv % 4) * f32(0.002)), (name, iu, iv)
+                if name in ONE_CHANNEL:
+                    # R/CRTTextureBitmap.cpp:27-31 reads buffer[index + 1] for green whatever the channel count: on the LAST texel of a
+                    # one-channel image that is one byte past stbi_load's buffer -- undefined, whatever the heap holds -- so that
+                    # sample is no known answer
+                    wI, hI = ONE_CHANNEL[name]
+                    uu, vv = min(max(f32(u), f32(0)), f32(1)), min(max(f32(v), f32(0)), f32(1))
+                    if int((f32(1) - vv) * f32(hI - 1)) == hI - 1 and int(uu * f32(wI - 1)) == wI - 1:
+                        continue
+                rgb = [int(round(c * 255.0)) for c in (r, g, b)]
+                assert all(f32(c) == f32(f32(q) / f32(255.0)) for c, q in zip((r, g, b), rgb)), (name, iu, iv, r, g, b)
+                rows.append([iu, iv] + rgb)
+        answers[name] = rows
+    with open(os.path.join(gold, "bitmap_known_answers.json"), "w") as f:
+        json.dump(answers, f, separators=(",", ":"))
     print("wrote", gold)
     return 0
+
+
+def _png(w, h, depth, color, rows, level=9, strategy=None, interlace=False, palette=None, trns=None, split_idat=1):
+    """rows: h byte strings of raw (unfiltered) scanline bytes.  Scanline y is filtered with type y % 5."""
+    import struct
+    import zlib
+    ch = {0: 1, 2: 3, 3: 1, 4: 2, 6: 4}[color]
+    bpp = max(1, ch * depth // 8)
+
+    def paeth(a, b, c):
+        p = a + b - c
+        pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+        return a if pa <= pb and pa <= pc else (b if pb <= pc else c)
+
+    def filtered(lines):
+        out = bytearray()
+        prev = None
+        for y, cur in enumerate(lines):
+            t = y % 5
+            out.append(t)
+            for i, v in enumerate(cur):
+                a = cur[i - bpp] if i >= bpp else 0
+                b = prev[i] if prev is not None else 0
+                c = prev[i - bpp] if (prev is not None and i >= bpp) else 0
+                pred = [0, a, b, (a + b) >> 1, paeth(a, b, c)][t]
+                out.append((v - pred) & 255)
+            prev = cur
+        return bytes(out)
+
+    if not interlace:
+        raw = filtered(rows)
+    else:
+        assert depth >= 8
+        x0, y0, dx, dy = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
+        px = ch * depth // 8
+        raw = b""
+        for p in range(7):
+            lines = []
+            for y in range(y0[p], h, dy[p]):
+                line = b"".join(rows[y][x * px:(x + 1) * px] for x in range(x0[p], w, dx[p]))
+                if line:
+                    lines.append(line)
+            if lines:
+                raw += filtered(lines)
+    co = zlib.compressobj(level, zlib.DEFLATED, 15, 8, zlib.Z_DEFAULT_STRATEGY if strategy is None else strategy)
+    z = co.compress(raw) + co.flush()
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, color, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", bytes(palette))
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    out += chunk(b"tEXt", b"Comment\0seeded test image")
+    n = max(1, len(z) // split_idat)
+    for i in range(0, len(z), n):
+        out += chunk(b"IDAT", z[i:i + n])
+    return out + chunk(b"IEND", b"")
+
+
+ONE_CHANNEL = {"tex_grey8_stored.png": (9, 6), "tex_grey1.png": (13, 6), "tex_grey8.tga": (9, 6)}  # name -> (width, height)
+
+
+def bitmap_fixtures():
+    import struct
+    import zlib
+    import numpy as np
+    rng = np.random.default_rng(23)
+    fx = {}
+    w, h = 9, 6
+    rgb = rng.integers(0, 256, size=(h, w, 3), dtype=np.uint8)
+    rgba = rng.integers(0, 256, size=(h, w, 4), dtype=np.uint8)
+    grey = rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+    fx["tex_rgb8.png"] = _png(w, h, 8, 2, [rgb[y].tobytes() for y in range(h)])
+    fx["tex_rgba8_fixed.png"] = _png(w, h, 8, 6, [rgba[y].tobytes() for y in range(h)], strategy=zlib.Z_FIXED)
+    fx["tex_grey8_stored.png"] = _png(w, h, 8, 0, [grey[y].tobytes() for y in range(h)], level=0)
+    ga = rng.integers(0, 256, size=(h, w, 2), dtype=np.uint8)
+    fx["tex_greyalpha8.png"] = _png(w, h, 8, 4, [ga[y].tobytes() for y in range(h)])
+    rgb16 = rng.integers(0, 65536, size=(h, w, 3), dtype=np.uint16)
+    fx["tex_rgb16.png"] = _png(w, h, 16, 2, [rgb16[y].astype(">u2").tobytes() for y in range(h)], split_idat=3)
+    big = rng.integers(0, 256, size=(19, 23, 3), dtype=np.uint8)
+    fx["tex_rgb8_adam7.png"] = _png(23, 19, 8, 2, [big[y].tobytes() for y in range(19)], interlace=True)
+    pal = rng.integers(0, 256, size=(16, 3), dtype=np.uint8)
+    idx = rng.integers(0, 16, size=(h, w), dtype=np.uint8)
+    rows4 = []
+    for y in range(h):
+        v = list(idx[y]) + [0] * (w % 2)
+        rows4.append(bytes((v[i] << 4) | v[i + 1] for i in range(0, len(v), 2)))
+    fx["tex_pal4.png"] = _png(w, h, 4, 3, rows4, palette=pal.reshape(-1).tolist())
+    fx["tex_pal4_trns.png"] = _png(w, h, 4, 3, rows4, palette=pal.reshape(-1).tolist(), trns=[0, 128, 255, 7])
+    bits = rng.integers(0, 2, size=(h, 13), dtype=np.uint8)
+    rows1 = [bytes(np.packbits(bits[y]).tolist()) for y in range(h)]
+    fx["tex_grey1.png"] = _png(13, h, 1, 0, rows1)
+    noisy = rng.integers(0, 256, size=(40, 64, 3), dtype=np.uint8)
+    noisy[:, :, 1] = (np.arange(64)[None, :] * 3 + np.arange(40)[:, None]) & 255   # compressible channel: long matches + literals
+    fx["tex_rgb8_big.png"] = _png(64, 40, 8, 2, [noisy[y].tobytes() for y in range(40)])
+
+    def bmp(w, h, bpp, rows_bgr, palette=None, top_down=False, v4=False):
+        stride = ((w * bpp + 31) // 32) * 4
+        body = b"".join(r + b"\0" * (stride - len(r)) for r in (rows_bgr if top_down else rows_bgr[::-1]))
+        pal = b"" if palette is None else b"".join(bytes([c[2], c[1], c[0], 0]) for c in palette)
+        hsz = 108 if v4 else 40
+        off = 14 + hsz + len(pal)
+        dib = struct.pack("<IiiHHIIiiII", hsz, w, -h if top_down else h, 1, bpp, 3 if v4 else 0, len(body), 2835, 2835, 0 if palette is None else len(palette), 0)
+        if v4:
+            dib += struct.pack("<IIII", 0x00FF0000, 0x0000FF00, 0x000000FF, 0xFF000000) + b"BGRs" + b"\0" * 48
+        return b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + dib + pal + body
+    fx["tex_24.bmp"] = bmp(w, h, 24, [rgb[y, :, ::-1].tobytes() for y in range(h)])
+    fx["tex_24_topdown.bmp"] = bmp(w, h, 24, [rgb[y, :, ::-1].tobytes() for y in range(h)], top_down=True)
+    bgra = rgba[:, :, [2, 1, 0, 3]]
+    fx["tex_32_v4.bmp"] = bmp(w, h, 32, [bgra[y].tobytes() for y in range(h)], v4=True)
+    pal8 = rng.integers(0, 256, size=(200, 3), dtype=np.uint8)
+    idx8 = rng.integers(0, 200, size=(h, w), dtype=np.uint8)
+    fx["tex_pal8.bmp"] = bmp(w, h, 8, [idx8[y].tobytes() for y in range(h)], palette=[tuple(int(x) for x in c) for c in pal8])
+
+    def tga(w, h, bpp, rows, kind, top_left=False, rle=False):
+        px = bpp // 8
+        data = b"".join(rows if top_left else rows[::-1])
+        if rle:
+            out = bytearray()
+            i, n = 0, w * h
+            while i < n:
+                run = 1
+                while i + run < n and run < 128 and data[(i + run) * px:(i + run + 1) * px] == data[i * px:(i + 1) * px]:
+                    run += 1
+                if run > 1:
+                    out.append(128 | (run - 1))
+                    out += data[i * px:(i + 1) * px]
+                    i += run
+                else:
+                    lit = 1
+                    while i + lit < n and lit < 128 and data[(i + lit) * px:(i + lit + 1) * px] != data[(i + lit - 1) * px:(i + lit) * px]:
+                        lit += 1
+                    out.append(lit - 1)
+                    out += data[i * px:(i + lit) * px]
+                    i += lit
+            data = bytes(out)
+        ident = b"seeded"
+        return struct.pack("<BBBHHBHHHHBB", len(ident), 0, kind + (8 if rle else 0), 0, 0, 0, 0, 0, w, h, bpp, (0x20 if top_left else 0) | (8 if bpp == 32 else 0)) + ident + data
+    fx["tex_24.tga"] = tga(w, h, 24, [rgb[y, :, ::-1].tobytes() for y in range(h)], 2)
+    flat = rgba.copy()
+    flat[2:4, 1:7] = flat[2, 1]   # runs for the run-length coder
+    fx["tex_32_rle_topleft.tga"] = tga(w, h, 32, [flat[y][:, [2, 1, 0, 3]].tobytes() for y in range(h)], 2, top_left=True, rle=True)
+    fx["tex_grey8.tga"] = tga(w, h, 8, [grey[y].tobytes() for y in range(h)], 3)
+    return fx
 
 
 if __name__ == "__main__":

@@ -47,6 +47,25 @@ static void putcam(FILE* f, const char* name, const CRTCamera& c, bool last = fa
 
 int main(int argc, char** argv)
 {
+    if (argc >= 4 && std::string(argv[1]) == "--bitmap") {
+        // known answers of the reference's CRTTextureBitmap (R/CRTTextureBitmap.cpp: stbi_load + getColor) for one image file:
+        // argv[2] = the file, argv[3] = output json: [[u, v, r, g, b], ...] on a 21 x 21 grid of (u, v)
+        FILE* f = fopen(argv[3], "w");
+        if (!f) return 3;
+        CRTTextureBitmap bmp(argv[2], "b");
+        fprintf(f, "[");
+        bool first = true;
+        for (int iu = 0; iu <= 20; iu++)
+            for (int iv = 0; iv <= 20; iv++) {
+                const float u = iu * 0.05f + (iu % 3) * 0.003f, v = iv * 0.05f + (iv % 4) * 0.002f;
+                const CRTVector c = bmp.getColor(u, v);
+                fprintf(f, "%s[%.9g,%.9g,%.9g,%.9g,%.9g]", first ? "" : ",", u, v, c.getX(), c.getY(), c.getZ());
+                first = false;
+            }
+        fprintf(f, "]\n");
+        fclose(f);
+        return 0;
+    }
     if (argc >= 4 && std::string(argv[1]) == "--textures") {
         // known answers of the reference's texture classes (R/CRTTexture*.cpp getColor): argv[2] = a bitmap the vendored
         // stb_image can read, argv[3] = output json
