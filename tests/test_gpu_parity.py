@@ -926,7 +926,8 @@ def test_scene_file_with_png_and_tga_textures_on_the_device(pkg, oracle, scenes,
         px = np.zeros((6, 9, 3), np.uint8)
         for row in range(6):
             for col in range(9):
-                c = s.texture_color(i, np.float32(col) / np.float32(8), np.float32(1) - np.float32(row) / np.float32(5))
+                # (aimed a quarter texel inside: the class truncates u * (w - 1) and (1 - v) * (h - 1), and clamps u, v to [0, 1])
+                c = s.texture_color(i, (np.float32(col) + np.float32(0.25)) / np.float32(8), np.float32(1) - (np.float32(row) + np.float32(0.25)) / np.float32(5))
                 px[row, col] = np.round(c * 255.0).astype(np.uint8)
         tex.append({"type": "bitmap", "pixels": px})
     meshes = [dict(vertices=m["vertices"], triangles=m["triangles"], normals=m["normals"], uvs=m["uvs"], material_index=m["material_index"]) for m in s.meshes()]
