@@ -82,11 +82,15 @@ struct crt_ctx {
     uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
     uint32_t tuneXcdGroup = 16;
     uint32_t tuneBoostUnits = 512;
-    // most expensive 8x8 packets rendered as four 4x4 quarters (render_kernels.hip).  Off by default: on the C3 frame 256 split
-    // packets take primary rays only (mode 3) from 0.204 to 0.187 ms but the Lambert + shadow frame from 0.294 to 0.307 ms (the
-    // quarters start first, while the chip is full, and trace their shadow rays at a quarter of the lane efficiency); the
-    // rank-share latency at 8 ranks moves from 188 to 182 us only: a packet's chain of dependent steps is its slowest RAY's
-    uint32_t tuneSplitUnits = 0;
+    // Split packets (split_packet.hip.h): the n most expensive 8x8 packets are rendered by 64 / split_rays wavefronts each whose
+    // lanes share the segments of the block's rays.  kSplitAuto (option value -1, the default): none for a whole frame on one GPU
+    // -- the launch order keeps the chip full there and splitting only adds work (C3: 0.299 -> 0.336 ms with 64 split) -- and 64 /
+    // 128 packets for a tile share of 2 / >= 4 ranks, whose lone launch lasts as long as its slowest wavefront: 221 -> 188, 199 -> 132,
+    // 178 -> 118 us at 2 / 4 / 8 ranks on the C3 frame (tools/split_probe.py).
+    static constexpr uint32_t kSplitAuto = 0xFFFFFFFFu;
+    uint32_t tuneSplitUnits = kSplitAuto;
+    uint32_t tuneSplitRaysLog2 = 2; // option "split_rays": 4 rays per wavefront of a split packet (16 wavefronts per packet)
+    uint32_t tuneSplitSegsLog2 = 4; // option "split_segments": 16 pieces per split ray
     bool tuneXcdAffine = false;
     uint32_t debugSkipUnits = 0;
     hipStream_t lastRenderStream = nullptr;
@@ -243,6 +247,8 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.xcd_group = c->tuneXcdGroup;
     p.boost_units = c->tuneBoostUnits;
     p.split_units = 0; // set in runRender once a launch order is in use
+    p.split_rays_log2 = c->tuneSplitRaysLog2;
+    p.split_segs_log2 = c->tuneSplitSegsLog2;
     p.debug_skip_units = c->debugSkipUnits;
     // LDS part of the per-lane stack: 16 entries x 64 lanes x 4 B = 4 KB per wavefront, so that LDS never limits the 7
     // wavefronts per SIMD the kernel's register budget allows (12 .. 20 entries measured alike, 24 costs 4 %); no ray of the
@@ -278,7 +284,7 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         if (p.mode >= 200u) p.path_tile = c->tunePathTile ? c->tunePathTile : 8u;
         // (+ 64 slices for each of the four wavefronts of a split packet)
         const size_t groups = p.mode >= 200u ? static_cast<size_t>(crt::pathGridSize(p))
-                                             : (static_cast<size_t>(crt::renderUnitCount(p)) + 4u * std::min(c->tuneSplitUnits, crt::renderUnitCount(p))) * p.n_batch;
+                                             : (static_cast<size_t>(crt::renderUnitCount(p)) + 16u * std::min(c->tuneSplitUnits == crt_ctx::kSplitAuto ? 128u : c->tuneSplitUnits, crt::renderUnitCount(p) / 4u)) * p.n_batch;
         const size_t need = groups * 64u * p.spill_stride * sizeof(int);
         if (c->spillBytes[slot] < need) {
             HIP_TRY(c, hipDeviceSynchronize());
@@ -355,7 +361,11 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         }
         const bool usable = c->orderKey[slot] == key;
         p.unit_order = usable ? c->dUnitOrder[slot] : nullptr;
-        p.split_units = usable ? std::min(c->tuneSplitUnits, nUnits) : 0u;
+        {
+            uint32_t want = c->tuneSplitUnits;
+            if (want == crt_ctx::kSplitAuto) want = p.n_ranks >= 4u ? 128u : (p.n_ranks >= 2u ? 64u : 0u);
+            p.split_units = usable ? std::min(want, nUnits / 4u) : 0u; // (at most a quarter of the packets: the spill arena below is sized for that)
+        }
         // Costs are measured (and sorted) twice in a row -- the first measurement ran under an unordered launch -- and then:
         // an unchanged view keeps its order for good; a view that keeps changing (a moving camera) measures again every
         // remeasure_every-th use of the slot.  Default 1: the order ages fast -- with a camera turning 0.01 degrees per frame
@@ -803,8 +813,16 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
         for (int i = 0; i < crt_ctx::kRing; i++) c->orderKey[i] = 0; // orders sorted the other way are stale
         return CRT_OK;
     }
-    if (std::strcmp(name, "split_units") == 0 && value >= 0 && value <= 65536) {
-        c->tuneSplitUnits = static_cast<uint32_t>(value);
+    if (std::strcmp(name, "split_units") == 0 && value >= -1 && value <= 65536) {
+        c->tuneSplitUnits = value < 0 ? crt_ctx::kSplitAuto : static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "split_rays") == 0 && (value == 4 || value == 8 || value == 16)) {
+        c->tuneSplitRaysLog2 = value == 4 ? 2u : (value == 8 ? 3u : 4u);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "split_segments") == 0 && (value == 4 || value == 8 || value == 16)) {
+        c->tuneSplitSegsLog2 = value == 4 ? 2u : (value == 8 ? 3u : 4u);
         return CRT_OK;
     }
     if (std::strcmp(name, "boost_units") == 0 && value >= 0) {

@@ -44,6 +44,8 @@ struct RenderParams {
     uint32_t boost_units;        // with unit_order: the first boost_units (most expensive) work units run at raised priority
     uint32_t split_units;        // with unit_order: the first split_units work units are rendered by FOUR wavefronts, one per 4x4
                                  // quarter of the 8x8 packet, every ray by four lanes (four segments of its way through the scene)
+    uint32_t split_rays_log2;    // rays (pixels) per wavefront of a split packet: 4 -> 16 (four wavefronts per packet), 3 -> 8, 2 -> 4 (sixteen)
+    uint32_t split_segs_log2;    // pieces a split ray is cut into: 2 -> 4, 3 -> 8, 4 -> 16
     float scene_lo[3], scene_hi[3]; // the scene's box (root of the tree): where a split ray's segments are cut
     uint32_t xcd_group;          // consecutive tiles of the list handed to one XCD before moving to the next (1..16, power of 2)
     // outputs (device pointers, nullable except rgba8)

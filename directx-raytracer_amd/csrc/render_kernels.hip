@@ -12,7 +12,7 @@
 //
 // Arithmetic contract: identical, operation for operation, to oracle/crt_oracle.c (compiled with
 // -ffp-contract=off; fused multiply-adds only where fmaf()/fma() is written; correctly rounded / and sqrt).
-#include "shading.hip.h"
+#include "split_packet.hip.h"
 
 namespace crt {
 namespace {
@@ -34,13 +34,15 @@ __device__ __forceinline__ void lanePixel(uint32_t wave, uint32_t quarter, uint3
     }
 }
 
-__device__ __forceinline__ uint32_t laneId() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+__device__ __forceinline__ uint32_t laneId() { return laneIndex(); }
 
 // SPLIT: the variant that can render split packets (below); launched only when the option "split_units" is non-zero, so that
 // the ordinary launch carries none of its code or registers (with it compiled into the one kernel, primary rays alone ran 5 %
 // slower and the kernel spilled 14 registers).
+// (The SPLIT variant is given 96 registers: the streams of a split quarter hold a ray in flight plus the hand-out state, and a
+// launch that splits packets is one whose chip is not full -- an N-rank tile share -- so five wavefronts per SIMD cost it nothing.)
 template <bool COUNT, bool PHONG, class L, bool SPLIT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L::kWavesPerEu, 8))) void renderKernel(const RenderParams p)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SPLIT ? 5 : L::kWavesPerEu, 8))) void renderKernel(const RenderParams p)
 {
     extern __shared__ int s_stack[]; // stack_entries x 256 dwords, sized at launch from the BVH depth
     unsigned long long t_start = 0;
@@ -64,25 +66,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L::kWavesPer
     const float* camRot = frame ? p.batch_rot[frame - 1u] : p.rot;
     uint32_t* outRgba8 = frame ? p.batch_rgba8[frame - 1u] : p.rgba8;
     uint32_t unit;
-    // Split packets: a frame lasts as long as its slowest packets, a packet as long as its slowest RAY (a grazing ray walks
-    // hundreds of dependent steps), and the launch order already knows which packets those are.  The split_units most
-    // expensive packets are rendered by four wavefronts each, one per 4x4 quarter, and every ray of a quarter by FOUR lanes:
-    // lane l + 16 k traces the ray of pixel l restricted to the k-th quarter of its way through the scene's box, (t_k, t_k+1)
-    // with the intervals overlapping by a rounding so that their union is the whole (tmin, tmax).  The closest hit of the ray
-    // is the hit of the first segment that has one -- same triangle, same t, u, v bit for bit, since a triangle's t does not
-    // depend on the interval it was found in and all candidates of an equal-t tie lie in the same segments -- and a shadow ray
-    // is occluded if any of its four segments is.  A chain of 380 dependent steps becomes four of about a hundred side by
-    // side: what an N-rank tile share needs, whose launch is as long as its slowest packet.  Results
-    // never change; the fetch counters of a split packet do (its rays re-descend from the root once per segment).
-    uint32_t quarter = 4u; // 4 = the whole 8x8 packet
+    // Split packets (split_packet.hip.h): the split_units most expensive packets are rendered by 64 / R wavefronts each, one per
+    // block of R = 1 << split_rays_log2 pixels, whose 64 lanes share the work of the block's rays.
+    uint32_t quarter = 64u; // part of a split packet; 64 = the whole 8x8 packet
     if (p.unit_order) {
         uint32_t pos = b;
         if (SPLIT) {
-            if (b < 4u * p.split_units) {
-                pos = b >> 2;
-                quarter = b & 3u;
+            const uint32_t partsLog2 = 6u - p.split_rays_log2;
+            if (b < (p.split_units << partsLog2)) {
+                pos = b >> partsLog2;
+                quarter = b & ((1u << partsLog2) - 1u);
             } else {
-                pos = b - 3u * p.split_units;
+                pos = b - ((p.split_units << partsLog2) - p.split_units);
             }
         }
         unit = p.unit_order[pos];
@@ -115,16 +110,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L::kWavesPer
         tile_y = k / p.tiles_x;
     }
     if (!valid) {
-        if (p.unit_cost && frame == 0u && threadIdx.x == 0 && quarter >= 4u) p.unit_cost[unit] = 0;
+        if (p.unit_cost && frame == 0u && threadIdx.x == 0 && quarter >= 64u) p.unit_cost[unit] = 0;
         return;
     }
 
     const uint32_t tid = threadIdx.x, wave = unit & 3u, lane = tid & 63u;
     uint32_t lx, ly;
-    lanePixel(wave, quarter, lane, lx, ly);
+    lanePixel(wave, 4u, lane, lx, ly);
     const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
     const bool active = (px < p.width) & (py < p.height);
-    const bool split = SPLIT && quarter < 4u; // wave-uniform
+    const bool split = SPLIT && quarter < 64u; // wave-uniform
 
     uint32_t cntNodes = 0, cntTris = 0, cntShadow = 0, cntClosest = 0;
 #if CRT_PROF
@@ -133,14 +128,20 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L::kWavesPer
     uint32_t pDv[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #endif
     uint32_t iters = 0; // traversal-loop iterations of this wavefront = its critical path, fed back as next frame's cost
-    if (active) {
+    if (split) {
+        Stack stack;
+        stack.lds = s_stack + tid;
+        // (a split packet's four wavefronts take the 64-lane slices behind those of the frame's ordinary units)
+        stack.spill = p.spill + ((static_cast<size_t>(p.units_per_frame) * p.n_batch + static_cast<size_t>(b) * p.n_batch + frame) * 64u + tid) * p.spill_stride;
+        stack.cap = static_cast<int>(p.stack_entries);
+        stack.sp = 0;
+        renderSplitQuarter<COUNT, PHONG, L>(p, camPos, camRot, outRgba8, frame, tile_x, tile_y, wave, quarter, p.split_rays_log2, p.split_segs_log2, stack, iters, cntNodes, cntTris, cntShadow, cntClosest);
+    } else if (active) {
         const float4* nodes = reinterpret_cast<const float4*>(p.nodes);
         const float4* tris = reinterpret_cast<const float4*>(p.tris);
         Stack stack;
         stack.lds = s_stack + tid;
-        // (a split packet's four wavefronts need 64 slices each: they take the slices of the padding units behind the frame's)
-        stack.spill = p.spill + ((split ? static_cast<size_t>(p.units_per_frame) * p.n_batch + static_cast<size_t>(b) * p.n_batch + frame
-                                        : static_cast<size_t>(frame) * p.units_per_frame + unit) * 64u + tid) * p.spill_stride;
+        stack.spill = p.spill + ((static_cast<size_t>(frame) * p.units_per_frame + unit) * 64u + tid) * p.spill_stride;
         stack.cap = static_cast<int>(p.stack_entries);
         stack.sp = 0;
 
@@ -150,31 +151,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L::kWavesPer
         {
             const F3 o = f3(camPos[0], camPos[1], camPos[2]);
             const Ray r = makeRay(o, rayDir(camRot, px, py, static_cast<float>(p.width), static_cast<float>(p.height)));
-            if (COUNT && (!split || lane < 16u)) cntClosest++;
-            if (!split) {
-                traceClosest<COUNT, L>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, iters, cntNodes, cntTris);
-            } else {
-                // a code path of its own (the mixed-octant loop: a few hundred wavefronts per frame), so that the per-lane interval
-                // costs the ordinary packets neither registers nor the constants folded into their loops
-                float tlo, thi;
-                segmentOf(r, p.scene_lo, p.scene_hi, kTMin, kTMax, lane >> 4, tlo, thi);
-                traceClosestOct<COUNT, L, 8>(nodes, tris, p.n_nodes, r, tlo, thi, stack, static_cast<int>(p.tune_inner_min), h, iters, cntNodes, cntTris);
-                // the ray's hit = the hit of its first segment that has one (lanes l, l + 16, l + 32, l + 48)
-                const unsigned long long found = __ballot(h.t < thi);
-                const uint32_t ray = laneId() & 15u; // (a fresh lane index: nothing of it is held during the traversal)
-                const uint32_t mine = static_cast<uint32_t>(found >> ray) & 0x00010001u, theirs = static_cast<uint32_t>(found >> (ray + 32u)) & 0x00010001u;
-                const uint32_t m4 = (mine & 1u) | ((mine >> 15) & 2u) | ((theirs & 1u) << 2) | ((theirs >> 13) & 8u);
-                const int src = static_cast<int>(ray + 16u * static_cast<uint32_t>(__builtin_ctz(m4 | 16u) & 3));
-                h.t = m4 ? __shfl(h.t, src, 64) : kTMax;
-                h.u = __shfl(h.u, src, 64);
-                h.v = __shfl(h.v, src, 64);
-                h.tri = static_cast<uint32_t>(__shfl(static_cast<int>(h.tri), src, 64));
-                h.gid = static_cast<uint32_t>(__shfl(static_cast<int>(h.gid), src, 64));
-            }
+            if (COUNT) cntClosest++;
+            traceClosest<COUNT, L>(nodes, tris, p.n_nodes, r, kTMin, kTMax, stack, static_cast<int>(p.tune_inner_min), h, iters, cntNodes, cntTris);
             col = f3(p.miss[0], p.miss[1], p.miss[2]); // miss shader (hlsl:72-76)
             if (h.t < kTMax) {
                 const float4* T = L::triPtr(tris, h.tri);
-                if (p.mode >= 100u) col = shadeLambert<COUNT, L, PHONG>(p, nodes, tris, r, h, stack, iters, cntNodes, cntTris, cntShadow, split);
+                if (p.mode >= 100u) col = shadeLambert<COUNT, L, PHONG>(p, nodes, tris, r, h, stack, iters, cntNodes, cntTris, cntShadow);
                 else col = shadeDebug(p.mode, __float_as_uint(T[0].w), __float_as_uint(T[1].w), h.t, h.u, h.v, r.o, r.d);
             }
         }
@@ -193,18 +175,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L::kWavesPer
         const uint32_t packed = unorm8(col.x) | (unorm8(col.y) << 8) | (unorm8(col.z) << 16) | 0xFF000000u;
         // where the pixel goes: recomputed from a fresh lane index, so that nothing of it is held (it was spilled) during the traversal
         uint32_t lx, ly;
-        lanePixel(wave, quarter, laneId(), lx, ly);
-        const bool writer = !split || laneId() < 16u; // the other three lanes of a split ray hold the same colour: one store per pixel
+        lanePixel(wave, 4u, laneId(), lx, ly);
         const uint32_t px = tile_x * kTile + lx, py = tile_y * kTile + ly;
         const size_t pix = static_cast<size_t>(py) * p.width + px;
-        if (!writer) {
-        } else
         if (p.staging) outRgba8[static_cast<size_t>((tile_y * p.tiles_x + tile_x) / p.n_ranks) * (kTile * kTile) + ly * kTile + lx] = packed;
         else outRgba8[pix] = packed;
-        if (p.hit_inst && frame == 0u && writer) p.hit_inst[pix] = inst;
-        if (p.hit_prim && frame == 0u && writer) p.hit_prim[pix] = prim;
-        if (p.hit_t && frame == 0u && writer) p.hit_t[pix] = hit ? h.t : kTMax;
-        if (p.rgb_f32 && frame == 0u && writer) {
+        if (p.hit_inst && frame == 0u) p.hit_inst[pix] = inst;
+        if (p.hit_prim && frame == 0u) p.hit_prim[pix] = prim;
+        if (p.hit_t && frame == 0u) p.hit_t[pix] = hit ? h.t : kTMax;
+        if (p.rgb_f32 && frame == 0u) {
             p.rgb_f32[3 * pix + 0] = col.x;
             p.rgb_f32[3 * pix + 1] = col.y;
             p.rgb_f32[3 * pix + 2] = col.z;
@@ -215,7 +194,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(L::kWavesPer
     // (a split packet reports the sum of its quarters' lifetimes into its slot, which the host zeroes before a measuring launch)
     if (p.unit_cost && frame == 0u && threadIdx.x == 0) {
         const uint32_t life = static_cast<uint32_t>((__builtin_amdgcn_s_memrealtime() - t_start) >> 6);
-        if (quarter < 4u) atomicAdd(&p.unit_cost[unit], life);
+        if (quarter < 64u) atomicAdd(&p.unit_cost[unit], life);
         else p.unit_cost[unit] = life;
     }
 #if CRT_DIAG
@@ -287,7 +266,8 @@ int launchRender(const RenderParams& p, bool counting, ihipStream_t* stream)
     const size_t lds = static_cast<size_t>(p.stack_entries) * 64u * sizeof(int);
     if (p.mode >= 200u) return launchPath(p, counting, stream); // path_kernels.hip
     {
-        const dim3 grid((n * 4u + (p.unit_order ? 3u * p.split_units : 0u)) * (p.n_batch ? p.n_batch : 1u));
+        const uint32_t extra = p.unit_order && p.split_units ? ((p.split_units << (6u - p.split_rays_log2)) - p.split_units) : 0u; // the further parts of split packets
+        const dim3 grid((n * 4u + extra) * (p.n_batch ? p.n_batch : 1u));
         const bool phong = p.mode >= 100u && p.phong_ks > 0.0f;
         const bool split = p.unit_order && p.split_units > 0u;
 #define CRT_LAUNCH2(LAY, SPL)                                                                                          \

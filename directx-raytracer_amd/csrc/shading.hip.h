@@ -181,34 +181,11 @@ __device__ __forceinline__ float powUint(float x, uint32_t n)
 
 // direct light at Po: one any-hit shadow ray per light with a positive cosine (oracle: direct_light).  PHONG (mode 100
 // only): plus the specular term ks * I / (4 pi r^2) * max(0, R . view)^n, R = the light direction mirrored about N.
-// A ray cut into four segments for the four lanes l, l + 16, l + 32, l + 48 of a split packet (render_kernels.hip): segment k
-// = the k-th quarter of [t0, t1], lower end moved down by a rounding so that neighbouring segments overlap and the union of the
-// four open intervals is all of (t0, t1).  Closest-hit rays: [t0, t1] = the ray's way through the scene's box, first segment
-// from tmin, last one up to tmax (so the union is (tmin, tmax) whatever the box test's rounding does).
-__device__ __forceinline__ void segmentRange(float t0, float t1, uint32_t seg, float& lo, float& hi)
-{
-    const float q = (t1 - t0) * 0.25f;
-    const float a = fmaf(q, static_cast<float>(seg), t0), b = fmaf(q, static_cast<float>(seg + 1u), t0);
-    lo = a - fabsf(a) * 0x1p-20f;
-    hi = b;
-}
-__device__ __forceinline__ void segmentOf(const Ray& r, const float* sceneLo, const float* sceneHi, float tmin, float tmax, uint32_t seg, float& lo, float& hi)
-{
-    const float x0 = fmaf(sceneLo[0], r.idir.x, r.noid.x), x1 = fmaf(sceneHi[0], r.idir.x, r.noid.x);
-    const float y0 = fmaf(sceneLo[1], r.idir.y, r.noid.y), y1 = fmaf(sceneHi[1], r.idir.y, r.noid.y);
-    const float z0 = fmaf(sceneLo[2], r.idir.z, r.noid.z), z1 = fmaf(sceneHi[2], r.idir.z, r.noid.z);
-    float t0 = fmaxf(fmaxf(fminf(x0, x1), fminf(y0, y1)), fmaxf(fminf(z0, z1), tmin));
-    float t1 = fminf(fminf(fmaxf(x0, x1), fmaxf(y0, y1)), fminf(fmaxf(z0, z1), tmax));
-    if (!(t0 <= t1)) t0 = t1 = tmin; // the ray misses the box (or NaN): every hit test below fails on its own, the split only has to stay a cover
-    segmentRange(t0, t1, seg, lo, hi);
-    if (seg == 0u) lo = tmin;
-    if (seg == 3u) hi = tmax;
-}
-
-// split (wave-uniform): lane l + 16 k traces only the k-th quarter of every shadow ray and the four lanes of a ray OR their findings
+// direct light at Po: one any-hit shadow ray per light with a positive cosine (oracle: direct_light).  PHONG (mode 100
+// only): plus the specular term ks * I / (4 pi r^2) * max(0, R . view)^n, R = the light direction mirrored about N.
 template <bool COUNT, class L, bool PHONG>
 __device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* nodes, const float4* tris, F3 Po, F3 N, F3 albedo, F3 view,
-                                          Stack& stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow, bool split = false)
+                                          Stack& stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
 {
     F3 rgb = f3(0.0f, 0.0f, 0.0f);
     const LightRec* lights = reinterpret_cast<const LightRec*>(p.lights);
@@ -222,20 +199,8 @@ __device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* n
         const float cosv = fmaxf(0.0f, dot3(N, Ld));
         if (cosv > 0.0f) {
             const Ray sr = makeRay(Po, Ld);
-            if (COUNT && (!split || (threadIdx.x & 63u) < 16u)) cntShadow++;
-            bool occluded;
-            if (!split) {
-                occluded = traceAny<COUNT, L>(nodes, tris, p.n_nodes, sr, 0.0f, dist, stack, static_cast<int>(p.tune_inner_min), iters, cntNodes, cntTris);
-            } else { // (wave-uniform: a split packet's lanes all carry a segment).  The four lanes of a ray took the same branches up to here.
-                float slo, shi;
-                const uint32_t seg = (threadIdx.x & 63u) >> 4;
-                segmentRange(0.0f, dist, seg, slo, shi);
-                if (seg == 3u) shi = dist;
-                occluded = traceAnyOct<COUNT, L, 8>(nodes, tris, p.n_nodes, sr, slo, shi, stack, static_cast<int>(p.tune_inner_min), iters, cntNodes, cntTris);
-                const unsigned long long occ = __ballot(occluded);
-                const uint32_t ray = (threadIdx.x & 15u);
-                occluded = (((occ >> ray) | (occ >> (ray + 16u)) | (occ >> (ray + 32u)) | (occ >> (ray + 48u))) & 1ull) != 0ull;
-            }
+            if (COUNT) cntShadow++;
+            const bool occluded = traceAny<COUNT, L>(nodes, tris, p.n_nodes, sr, 0.0f, dist, stack, static_cast<int>(p.tune_inner_min), iters, cntNodes, cntTris);
             if (!occluded) {
                 const float k = (Lt.intensity / (kFourPi * r2)) * cosv;
                 rgb.x = fmaf(albedo.x, k, rgb.x);
@@ -257,10 +222,10 @@ __device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* n
 // mode 100: Lambert (+ optional Phong highlight) + one shadow ray per light, every material treated as diffuse (oracle: shade_lambert)
 template <bool COUNT, class L, bool PHONG>
 __device__ __forceinline__ F3 shadeLambert(const RenderParams& p, const float4* nodes, const float4* tris, const Ray& r,
-                                           const Hit& h, Stack& stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow, bool split = false)
+                                           const Hit& h, Stack& stack, uint32_t& iters, uint32_t& cntNodes, uint32_t& cntTris, uint32_t& cntShadow)
 {
     const Surface sf = surfaceAt<L>(p, tris, r, h);
-    return directLight<COUNT, L, PHONG>(p, nodes, tris, biasPoint(sf.P, sf.N, kShadowBias), sf.N, sf.albedo, f3(-r.d.x, -r.d.y, -r.d.z), stack, iters, cntNodes, cntTris, cntShadow, split);
+    return directLight<COUNT, L, PHONG>(p, nodes, tris, biasPoint(sf.P, sf.N, kShadowBias), sf.N, sf.albedo, f3(-r.d.x, -r.d.y, -r.d.z), stack, iters, cntNodes, cntTris, cntShadow);
 }
 
 // ---- mode 200: path tracing (oracle: trace_path). Counter-based RNG keyed by (pixel, sample, seed).

@@ -218,9 +218,11 @@ int crt_render_frame_distributed(crt_ctx* ctx, uint32_t width, uint32_t height, 
  * change): "inner_min" 1..65 wave scheduling of the traversal loop, "xcd_group", "adaptive_order" (launch the most expensive 8x8
  * packets of the previous frame first: 0 never, 1 always, 2 = default: only for a frame issued on the same stream as the frame
  * before, where frames run one after another), "remeasure_every" (a moving camera re-measures packet costs every n-th use of a scratch slot; default 1), "boost_units",
- * "split_units" (with a launch order: the n most expensive 8x8 packets are rendered by four wavefronts, one per 4x4 quarter, every
- * ray by four lanes that each trace a quarter of its way through the scene -- same frame, shorter critical path: the lone launch of
- * an 8-rank tile share of primary rays goes from 144 to 104 us; fetch counters of split packets grow; default 0 = off),
+ * "split_units" (with a launch order: the n most expensive 8x8 packets are rendered by several wavefronts each, whose lanes
+ * share the pieces of the block's rays -- same frame, shorter critical path; -1 = automatic, the default: none for a whole frame
+ * on one GPU, 64 / 128 packets for the tile share of 2 / >= 4 ranks, whose lone launch goes from 221 / 199 / 178 us to 188 / 132 /
+ * 118 us at 2 / 4 / 8 ranks; 0 = off; fetch counters of split packets grow), "split_rays" (16, 8 or 4 rays per wavefront of a
+ * split packet, default 4), "split_segments" (4, 8 or 16 pieces per split ray, default 16),
  * "xcd_affine_order" 0/1 (with a launch order: the frame is cut into eight regions of equal cost, one per XCD and its L2, each launched
  * most expensive packet first; default 0 -- primary rays alone gain 5 %, a shaded frame loses 1 %),
  * "path_tile" (mode 200 work split: pixel-tile edge per workgroup, 8 (default, also 0) or 16), "stack_entries" (0 = default 16; deeper entries spill to a

@@ -1130,6 +1130,15 @@ void oracle_shade_mode(uint32_t mode, uint32_t inst, uint32_t prim, float t, flo
     out_rgb[0] = c.x; out_rgb[1] = c.y; out_rgb[2] = c.z;
 }
 
+/* any-hit query on an arbitrary ray interval (tests: the segments of split packets, csrc/split_packet.hip.h) */
+int oracle_occluded(const oracle_scene* s, const float o[3], const float d[3], float tmin, float tmax, int brute)
+{
+    ray r;
+    ray_setup(&r, v3_make(o[0], o[1], o[2]), v3_make(d[0], d[1], d[2]));
+    trav_count c = { 0, 0 };
+    return brute ? brute_any(s, &r, tmin, tmax, &c) : trace_any(s, &r, tmin, tmax, &c);
+}
+
 int oracle_intersect_tri(const float o[3], const float d[3], const float v0[3], const float v1[3],
                          const float v2[3], float tmin, float tmax, float* t, float* u, float* v)
 {

@@ -168,6 +168,7 @@ void oracle_shade_mode(uint32_t mode, uint32_t inst, uint32_t prim, float t, flo
                        const float o[3], const float d[3], float out_rgb[3]);
 uint8_t oracle_unorm8(float c);
 /* one triangle, Moeller-Trumbore as specified; returns 1 on hit with t in (tmin, tmax) */
+int oracle_occluded(const oracle_scene* s, const float o[3], const float d[3], float tmin, float tmax, int brute);
 int oracle_intersect_tri(const float o[3], const float d[3], const float v0[3], const float v1[3],
                          const float v2[3], float tmin, float tmax, float* t, float* u, float* v);
 int oracle_max_threads(void);

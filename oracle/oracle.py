@@ -295,6 +295,14 @@ class OracleScene:
         return out
 
 
+def occluded(scene, o, d, tmin, tmax, brute_force=False):
+    """any-hit query on the open interval (tmin, tmax) of the ray o + t d: 1 if some triangle lies in it"""
+    L = lib()
+    L.oracle_occluded.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int]
+    o, d = _f32(o, 3), _f32(d, 3)
+    return int(L.oracle_occluded(scene.h, o.ctypes.data, d.ctypes.data, float(np.float32(tmin)), float(np.float32(tmax)), int(bool(brute_force))))
+
+
 def ray_dir(rot, px, py, w, h):
     rot = _f32(rot, 9)
     o = np.zeros(3, dtype=np.float32)

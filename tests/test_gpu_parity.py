@@ -382,12 +382,15 @@ def test_scheduling_knobs_never_change_results(pkg, oracle, scenes, dragon, rend
     renderer.change_shading_mode(100)
     w, h = 640, 360
     ref = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"]).render(cam["position"], cam["matrix"], 100, w, h)
-    defaults = {"inner_min": 32, "xcd_group": 16, "adaptive_order": 2, "boost_units": 512, "split_units": 0, "xcd_affine_order": 0, "stack_entries": 0}
+    defaults = {"inner_min": 32, "xcd_group": 16, "adaptive_order": 2, "boost_units": 512, "split_units": -1, "split_rays": 4, "split_segments": 16,
+                "xcd_affine_order": 0, "stack_entries": 0}
     try:
         for name, values in (("inner_min", (1, 7, 33, 65)), ("xcd_group", (1, 4)), ("adaptive_order", (0, 1, 2)),
-                             ("boost_units", (0, 100000)), ("split_units", (0, 7, 3000, 65536)), ("xcd_affine_order", (1,)), ("stack_entries", (1, 2, 5, 16, 32))):  # 1..5: the spill arena carries most of the stack
+                             ("boost_units", (0, 100000)), ("split_units", (0, 7, 3000, 65536)), ("split_rays", (16, 8)), ("split_segments", (4, 8)), ("xcd_affine_order", (1,)), ("stack_entries", (1, 2, 5, 16, 32))):  # 1..5: the spill arena carries most of the stack
             for v in values:
                 renderer.set_option(name, v)
+                if name in ("split_rays", "split_segments"):
+                    renderer.set_option("split_units", 40)  # (these two only act on split packets)
                 renderer.set_counting(True)
                 for frame in range(10):  # from frame 4 on (ring of 4 slots) the launch order comes from an earlier frame's costs
                     got = renderer.render_frame(w, h)
@@ -395,13 +398,14 @@ def test_scheduling_knobs_never_change_results(pkg, oracle, scenes, dragon, rend
                         np.testing.assert_array_equal(got[k], ref[k], err_msg="%s=%d frame %d %s" % (name, v, frame, k))
                     assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True)
                     assert got["stats"]["rays_primary"] == ref["stats"]["rays_primary"] and got["stats"]["rays_shadow"] == ref["stats"]["rays_shadow"]
-                    if name == "split_units" and v > 0:
+                    if name in ("split_units", "split_rays", "split_segments") and (v > 0 if name == "split_units" else True):
                         # a split packet's rays are traced as four segments that each descend from the root: same hits, more fetches
                         assert got["stats"]["nodes_visited"] >= ref["stats"]["nodes_visited"]
                     else:
                         assert got["stats"]["nodes_visited"] == ref["stats"]["nodes_visited"]
                         assert got["stats"]["tris_tested"] == ref["stats"]["tris_tested"]
             renderer.set_option(name, defaults[name])
+            renderer.set_option("split_units", defaults["split_units"])
         with pytest.raises(pkg.CrtError):
             renderer.set_option("no_such_option", 1)
         with pytest.raises(pkg.CrtError):
@@ -413,10 +417,11 @@ def test_scheduling_knobs_never_change_results(pkg, oracle, scenes, dragon, rend
 
 
 def test_split_packets_render_the_same_frame(pkg, oracle, scenes, renderer):
-    """Option split_units: the most expensive 8x8 packets are rendered by four wavefronts, every ray by four lanes that each trace
-    a quarter of its way through the scene (closest hit = first segment with a hit; a shadow ray is occluded if any segment is).
-    C3 scene, whole frame and an 8-rank tile share, primary rays only and with shadow rays (plain and Phong): hit ids, t and
-    colours are the oracle's bit for bit."""
+    """Split packets (split_packet.hip.h; options split_units / split_rays / split_segments; on by default for the tile share of a
+    multi-rank frame): the most expensive 8x8 packets are rendered by 4 / 8 / 16 wavefronts whose lanes share the segments of
+    the block's rays (closest hit = lowest segment with a hit; a shadow ray is occluded if any segment is).  C3 scene, whole frame
+    and an 8-rank tile share, primary rays only and with shadow rays (plain and Phong): hit ids, t and colours are the oracle's
+    bit for bit."""
     import torch
     sc = scenes.heightfield(n_lights=1)
     cam = sc["camera"]
@@ -430,14 +435,19 @@ def test_split_packets_render_the_same_frame(pkg, oracle, scenes, renderer):
             renderer.set_option("phong_ks", phong)
             oracle.set_phong(phong, 32)
             ref = O.render(cam["position"], cam["matrix"], mode, w, h)
-            for split in (300, 4096):
+            for split, rays, segs in ((300, 4, 16), (4096, 16, 4), (150, 8, 8)):
                 renderer.set_option("split_units", split)
+                renderer.set_option("split_rays", rays)
+                renderer.set_option("split_segments", segs)
                 for frame in range(10):  # the launch order (and with it the split) comes from an earlier frame's costs
                     got = renderer.render_frame(w, h)
                 for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
-                    np.testing.assert_array_equal(got[k], ref[k], err_msg="mode %d phong %d split %d %s" % (mode, phong, split, k))
+                    np.testing.assert_array_equal(got[k], ref[k], err_msg="mode %d phong %d split %d x %d x %d %s" % (mode, phong, split, rays, segs, k))
                 assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True)
-            # an 8-rank share (what the split is for: its launch lasts as long as its slowest packet)
+            # an 8-rank share with the default setting (what the split is for: its launch lasts as long as its slowest packet)
+            renderer.set_option("split_units", -1)
+            renderer.set_option("split_rays", 4)
+            renderer.set_option("split_segments", 16)
             n = 8
             slots = pkg.tile_slots(w, h, n)
             gathered = torch.zeros(n * slots * 256, dtype=torch.int32, device="cuda")
@@ -450,9 +460,42 @@ def test_split_packets_render_the_same_frame(pkg, oracle, scenes, renderer):
             renderer.synchronize()
             np.testing.assert_array_equal(frame_t.cpu().numpy().view(np.uint32).reshape(h, w), ref["rgba8"].view(np.uint32).reshape(h, w))
     finally:
-        renderer.set_option("split_units", 0)
+        renderer.set_option("split_units", -1)
+        renderer.set_option("split_rays", 4)
+        renderer.set_option("split_segments", 16)
         renderer.set_option("phong_ks", 0)
         oracle.set_phong(0, 32)
+        renderer.change_shading_mode(0)
+
+
+def test_split_packets_stress(pkg, oracle, scenes, dragon, renderer):
+    """A quarter of all packets split, every combination of rays per wavefront and pieces per ray, on scenes with several lights,
+    smooth normals, tiny and huge triangles and rays that start inside boxes: hit ids, t and colours stay the oracle's."""
+    cases = [(_with_normals(scenes, dragon), 640, 360, (3, 100)), (scenes.cornell_box(), 256, 256, (100,)),
+             (scenes.displaced_sphere(n_lat=60, n_lon=80), 480, 270, (0, 100))]
+    try:
+        for sc, w, h, modes in cases:
+            cam = sc["camera"]
+            renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+            renderer.set_camera(cam["position"], cam["matrix"])
+            O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+            for mode in modes:
+                renderer.change_shading_mode(mode)
+                ref = O.render(cam["position"], cam["matrix"], mode, w, h)
+                for rays in (4, 8, 16):
+                    for segs in (4, 8, 16):
+                        renderer.set_option("split_units", 65536)
+                        renderer.set_option("split_rays", rays)
+                        renderer.set_option("split_segments", segs)
+                        for frame in range(9):
+                            got = renderer.render_frame(w, h)
+                        for k in ("hit_inst", "hit_prim", "hit_t", "rgba8"):
+                            np.testing.assert_array_equal(got[k], ref[k], err_msg="mode %d, %d rays x %d segments: %s" % (mode, rays, segs, k))
+                        assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True)
+    finally:
+        renderer.set_option("split_units", -1)
+        renderer.set_option("split_rays", 4)
+        renderer.set_option("split_segments", 16)
         renderer.change_shading_mode(0)
 
 

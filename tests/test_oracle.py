@@ -374,3 +374,34 @@ def test_wide_and_binary_traversal_agree(oracle, scenes, dragon):
             assert np.array_equal(a[k], b[k]), k
         assert a["stats"]["rays_shadow"] == b["stats"]["rays_shadow"]
         assert a["stats"]["nodes_visited"] < 0.75 * b["stats"]["nodes_visited"]
+
+
+def test_ray_segments_cover_the_ray(oracle, scenes, dragon):
+    """The idea behind split packets (csrc/split_packet.hip.h), on the oracle: a ray cut into K overlapping pieces is occluded
+    exactly when one of its pieces is, BVH walk and brute force alike -- also for pieces that start in the middle of the geometry
+    (a lower bound inside boxes and just in front of triangles)."""
+    O = oracle.OracleScene(dragon["meshes"], dragon["lights"], dragon["materials"])
+    rng = np.random.default_rng(3)
+    f32 = np.float32
+    n_occluded = 0
+    for _ in range(400):
+        o = f32(rng.uniform(-14, 14, 3)); o[1] = f32(rng.uniform(-5, 9))
+        target = f32(rng.uniform(-6, 6, 3))
+        d = target - o
+        dist = f32(np.sqrt((d * d).sum(dtype=f32)))
+        d = (d / dist).astype(f32)
+        whole = oracle.occluded(O, o, d, 0.0, dist)
+        assert whole == oracle.occluded(O, o, d, 0.0, dist, brute_force=True)
+        n_occluded += whole
+        for K in (4, 16):
+            q = dist / f32(K)
+            pieces = 0
+            for k in range(K):
+                a, b = q * f32(k), q * f32(k + 1)
+                lo = f32(0) if k == 0 else a - abs(a) * f32(2.0 ** -10)
+                hi = dist if k == K - 1 else b
+                got = oracle.occluded(O, o, d, lo, hi)
+                assert got == oracle.occluded(O, o, d, lo, hi, brute_force=True)
+                pieces |= got
+            assert pieces == whole
+    assert 40 < n_occluded < 360
