@@ -78,7 +78,12 @@ struct crt_ctx {
     uint32_t pathSpp = 4, pathBounces = 3, pathSeed = 1234; // mode 200 (BASELINE.json configs[4]: 4 spp, 3 bounces)
     uint32_t phongKsPermille = 0, phongExp = 32;            // mode 100: specular term, off by default
     uint32_t tunePathTile = 0;     // mode 200 work split: 0 = default (8), 8 / 16 = pixel tile edge per workgroup
-    uint32_t tuneInnerMin = 32;    // wave scheduling threshold of the traversal loop (traversal.hip.h)
+    // wave scheduling threshold of the closest-hit traversal loop (traversal.hip.h closestIteration; an int: > 0 = node steps while
+    // that many lanes stand on inner nodes, -k = while k eighths of the wavefront's LIVE lanes do) and of the any-hit loop.
+    // -6 against round 2's fixed 32: primary rays only 0.193 -> 0.172 ms, icosphere soup 0.256 -> 0.231, 5M triangles 0.367 -> 0.352,
+    // C3 with shadow rays 0.2866 -> 0.2847, path tracing C5 22.6 -> 22.0 ms, lone launch of an 8-rank share 181 -> 174 us
+    uint32_t tuneInnerMin = static_cast<uint32_t>(-6);
+    uint32_t tuneInnerMinAny = static_cast<uint32_t>(-6);
     uint32_t tuneStackEntries = 0; // 0 = from the BVH depth
     uint32_t tuneXcdGroup = 16;
     uint32_t tuneBoostUnits = 512;
@@ -244,6 +249,7 @@ void fillParams(const crt_ctx* c, uint32_t w, uint32_t h, uint32_t rank, uint32_
     p.spill = nullptr;
     p.unit_cost = nullptr;
     p.tune_inner_min = c->tuneInnerMin;
+    p.tune_inner_min_any = c->tuneInnerMinAny;
     p.xcd_group = c->tuneXcdGroup;
     p.boost_units = c->tuneBoostUnits;
     p.split_units = 0; // set in runRender once a launch order is in use
@@ -800,8 +806,12 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
         c->tunePathTile = static_cast<uint32_t>(value);
         return CRT_OK;
     }
-    if (std::strcmp(name, "inner_min") == 0 && value >= 1 && value <= 65) {
+    if (std::strcmp(name, "inner_min") == 0 && value >= -8 && value <= 65 && value != 0) { // negative: adaptive, eighths of the live lanes
         c->tuneInnerMin = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "inner_min_any") == 0 && value >= -8 && value <= 65 && value != 0) {
+        c->tuneInnerMinAny = static_cast<uint32_t>(value);
         return CRT_OK;
     }
     if (std::strcmp(name, "xcd_group") == 0 && (value == 1 || value == 2 || value == 4 || value == 8 || value == 16)) {

@@ -381,7 +381,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
         // ---- stages B / C until no path is left
         while (nShade != 0u) {
             uint32_t nTrace = 0;
-            streamShade<COUNT, L>(p, nodes, tris, q, nShade, nTrace, stack, innerMin, iters, cntNodes, cntTris, cntShadow); // stage B
+            streamShade<COUNT, L>(p, nodes, tris, q, nShade, nTrace, stack, static_cast<int>(p.tune_inner_min_any), iters, cntNodes, cntTris, cntShadow); // stage B
             nShade = 0;
             streamClosest<COUNT, L>(nodes, tris, p.n_nodes, q, nTrace, nShade, miss, stack, innerMin, iters, cntNodes, cntTris, cntClosest); // stage C
         }

@@ -38,7 +38,8 @@ struct RenderParams {
     uint32_t rank, n_ranks;      // this launch renders macro tiles k with k % n_ranks == rank
     uint32_t n_local_tiles;      // grid size: number of such tiles
     uint32_t staging;            // 0: write row-major frame buffers; 1: rgba8 goes to the tile-major staging buffer
-    uint32_t tune_inner_min;     // wave scheduling knob, see traceClosest()
+    uint32_t tune_inner_min;     // wave scheduling knob of the closest-hit traversal, see closestIteration() (int: negative = adaptive)
+    uint32_t tune_inner_min_any; // the same for the any-hit (shadow ray) traversal
     uint32_t stack_entries;      // per-lane stack entries kept in LDS; deeper ones go to the spill arena
     uint32_t debug_skip_units;   // diagnostics: with unit_order, the first N work units are not rendered
     uint32_t boost_units;        // with unit_order: the first boost_units (most expensive) work units run at raised priority

@@ -200,7 +200,7 @@ __device__ __forceinline__ F3 directLight(const RenderParams& p, const float4* n
         if (cosv > 0.0f) {
             const Ray sr = makeRay(Po, Ld);
             if (COUNT) cntShadow++;
-            const bool occluded = traceAny<COUNT, L>(nodes, tris, p.n_nodes, sr, 0.0f, dist, stack, static_cast<int>(p.tune_inner_min), iters, cntNodes, cntTris);
+            const bool occluded = traceAny<COUNT, L>(nodes, tris, p.n_nodes, sr, 0.0f, dist, stack, static_cast<int>(p.tune_inner_min_any), iters, cntNodes, cntTris);
             if (!occluded) {
                 const float k = (Lt.intensity / (kFourPi * r2)) * cosv;
                 rgb.x = fmaf(albedo.x, k, rgb.x);

@@ -202,7 +202,7 @@ __device__ __forceinline__ void renderSplitQuarter(const RenderParams& p, const 
             if (COUNT && need) cntShadow++;
             Hit unusedHit;
             bool occluded;
-            splitStream<COUNT, L, false>(nodes, tris, p.n_nodes, Po, Ld, 0.0f, dist, need, 0.0f, dist, raysLog2, segsLog2, stack, innerMin, unusedHit, occluded, iters, cntNodes, cntTris);
+            splitStream<COUNT, L, false>(nodes, tris, p.n_nodes, Po, Ld, 0.0f, dist, need, 0.0f, dist, raysLog2, segsLog2, stack, static_cast<int>(p.tune_inner_min_any), unusedHit, occluded, iters, cntNodes, cntTris);
             if (need && !occluded) {
                 const float k = (Lt.intensity / (kFourPi * r2)) * cosv;
                 rgb.x = fmaf(sf.albedo.x, k, rgb.x);

@@ -637,7 +637,11 @@ __device__ __forceinline__ void loadTriUniform(const float4* T, float4& a, float
 // and counters do not depend on what the other lanes do), but WHEN a lane's next step runs is decided per wavefront:
 // node steps are issued while at least `innerMin` lanes still stand on inner nodes (or nobody waits at a leaf); then the
 // lanes waiting at leaves intersect their triangles.  innerMin = 1 is the classic while-while loop (leaves wait until
-// every lane has one: 47 % of the lanes active on the 1M-triangle frame); 32 measured best (first measurement: 0.67 vs 1.10 ms; re-swept after every structural change).
+// every lane has one: 47 % of the lanes active on the 1M-triangle frame); a fixed 32 was the setting of rounds 1 and 2 (first
+// measurement: 0.67 vs 1.10 ms).  Round 3: the threshold follows the wavefront's LIVE lanes -- three quarters of them -- because
+// late in a packet's life most rays have finished, fewer than 32 lanes are left on inner nodes whatever happens, and a fixed 32
+// then serves every single lane that reaches a leaf at once, a whole pass of the wavefront for one or two lanes: primary rays only
+// 0.193 -> 0.172 ms, soup 0.256 -> 0.231, the longest packets shorten most (lone launch of an 8-rank share of primary rays 141 -> 126 us).
 // One scheduling decision of the closest-hit traversal for the whole wavefront: NODE_STEPS node steps of the lanes standing
 // on inner nodes, or the leaf step of the lanes waiting at leaves.  Per-lane state (cur, stack, h, tcull) lives in the
 // caller, so a caller may retire finished rays and start new ones between two calls (streamClosest).  Returns false when
@@ -651,7 +655,11 @@ __device__ __forceinline__ bool closestIteration(const float4* __restrict__ node
     const unsigned long long leafMask = __ballot(L::leaf(cur));
     if ((innerMask | leafMask) == 0ull) return false;
     if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3); // a wavefront on a long critical path stops queueing behind the others
-    if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
+    // innerMin > 0: node steps while at least that many lanes stand on inner nodes; innerMin <= 0 (adaptive): while at least
+    // (live lanes * -innerMin) / 8 do (live = lanes with anything left to do), so that a wavefront whose rays have mostly finished
+    // does not fall back to serving every single waiting leaf at once
+    const int wantNode = innerMin > 0 ? innerMin : (static_cast<int>(__popcll(innerMask | leafMask)) * -innerMin + 7) / 8;
+    if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= wantNode)) {
 #if CRT_PROF
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif
@@ -768,7 +776,11 @@ __device__ __forceinline__ bool anyIteration(const float4* __restrict__ nodes, c
     const unsigned long long leafMask = __ballot(L::leaf(cur));
     if ((innerMask | leafMask) == 0ull) return false;
     if (++iters == kBoostAfter) __builtin_amdgcn_s_setprio(3);
-    if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= innerMin)) {
+    // innerMin > 0: node steps while at least that many lanes stand on inner nodes; innerMin <= 0 (adaptive): while at least
+    // (live lanes * -innerMin) / 8 do (live = lanes with anything left to do), so that a wavefront whose rays have mostly finished
+    // does not fall back to serving every single waiting leaf at once
+    const int wantNode = innerMin > 0 ? innerMin : (static_cast<int>(__popcll(innerMask | leafMask)) * -innerMin + 7) / 8;
+    if (innerMask != 0ull && (leafMask == 0ull || static_cast<int>(__popcll(innerMask)) >= wantNode)) {
 #if CRT_PROF
         const unsigned long long ts0 = __builtin_amdgcn_s_memtime();
 #endif

@@ -215,7 +215,8 @@ int crt_render_frame_distributed(crt_ctx* ctx, uint32_t width, uint32_t height, 
  * mirrored about the shading normal, V = direction to the eye; white highlight, x^n by square and multiply.
  * "gpu_build" 0/1: acceleration structure built on the GPU (LBVH) at the next crt_upload_scene.
  * Rendering parameters of mode 200: "spp", "max_bounces", "seed". Tuning knobs (speed only, results never
- * change): "inner_min" 1..65 wave scheduling of the traversal loop, "xcd_group", "adaptive_order" (launch the most expensive 8x8
+ * change): "inner_min" / "inner_min_any" wave scheduling of the closest-hit / any-hit traversal loops (1..65: node steps while that
+ * many lanes stand on inner nodes; -1..-8: while that many eighths of the wavefront's live lanes do; default -6), "xcd_group", "adaptive_order" (launch the most expensive 8x8
  * packets of the previous frame first: 0 never, 1 always, 2 = default: only for a frame issued on the same stream as the frame
  * before, where frames run one after another), "remeasure_every" (a moving camera re-measures packet costs every n-th use of a scratch slot; default 1), "boost_units",
  * "split_units" (with a launch order: the n most expensive 8x8 packets are rendered by several wavefronts each, whose lanes

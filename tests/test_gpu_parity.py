@@ -382,10 +382,10 @@ def test_scheduling_knobs_never_change_results(pkg, oracle, scenes, dragon, rend
     renderer.change_shading_mode(100)
     w, h = 640, 360
     ref = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"]).render(cam["position"], cam["matrix"], 100, w, h)
-    defaults = {"inner_min": 32, "xcd_group": 16, "adaptive_order": 2, "boost_units": 512, "split_units": -1, "split_rays": 4, "split_segments": 16,
+    defaults = {"inner_min": -6, "inner_min_any": -6, "xcd_group": 16, "adaptive_order": 2, "boost_units": 512, "split_units": -1, "split_rays": 4, "split_segments": 16,
                 "xcd_affine_order": 0, "stack_entries": 0}
     try:
-        for name, values in (("inner_min", (1, 7, 33, 65)), ("xcd_group", (1, 4)), ("adaptive_order", (0, 1, 2)),
+        for name, values in (("inner_min", (1, 7, 33, 65, -1, -3, -8)), ("inner_min_any", (1, 32, -2, -8)), ("xcd_group", (1, 4)), ("adaptive_order", (0, 1, 2)),
                              ("boost_units", (0, 100000)), ("split_units", (0, 7, 3000, 65536)), ("split_rays", (16, 8)), ("split_segments", (4, 8)), ("xcd_affine_order", (1,)), ("stack_entries", (1, 2, 5, 16, 32))):  # 1..5: the spill arena carries most of the stack
             for v in values:
                 renderer.set_option(name, v)

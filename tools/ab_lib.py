@@ -11,6 +11,7 @@ def main():
     ap.add_argument("--opt", default=None, help="name=v1,v2,...: also sweep a crt_set_option knob for every library")
     ap.add_argument("--scene", default="heightfield", help="heightfield (C3) | heightfield5m | soup")
     ap.add_argument("--rounds", type=int, default=6); ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--set", action="append", default=[], help="name=value set once on every renderer")
     a = ap.parse_args()
     import torch
     pkg = entry.load_package(); scenes = importlib.import_module(entry.PKG_NAME + ".scenes")
@@ -23,6 +24,7 @@ def main():
         pkg._lib = None; pkg.LIB_PATH = os.path.abspath(path)
         L = pkg.lib()
         r = pkg.Renderer(0); r.upload(sc["meshes"], sc["lights"], sc["materials"]); r.set_camera(sc["camera"]["position"], sc["camera"]["matrix"]); r.change_shading_mode(a.mode)
+        for o in a.set: r.set_option(o.split("=")[0], int(o.split("=")[1]))
         rs.append((path, L, r))
     oname, ovals = (a.opt.split("=")[0], [int(v) for v in a.opt.split("=")[1].split(",")]) if a.opt else (None, [None])
     res = {(p, v): [] for p, _, _ in rs for v in ovals}

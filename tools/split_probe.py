@@ -11,12 +11,14 @@ def main():
     ap = argparse.ArgumentParser(); ap.add_argument("--mode", type=int, default=100); ap.add_argument("--splits", default="0,64,128,256,512,1024")
     ap.add_argument("--rays", default="4", help="rays per wavefront of a split packet: 16, 8 or 4 (comma separated to sweep)")
     ap.add_argument("--ranks", default="1,8")
+    ap.add_argument("--set", action="append", default=[], help="name=value set once on the renderer")
     ap.add_argument("--segments", default="16", help="pieces per split ray: 4, 8 or 16 (comma separated to sweep)")
     a = ap.parse_args()
     pkg = e.load_package(); scenes = importlib.import_module(e.PKG_NAME + ".scenes"); host = importlib.import_module(e.PKG_NAME + ".multigpu")
     if os.environ.get("CRT_LIB"): pkg.LIB_PATH = os.path.abspath(os.environ["CRT_LIB"])
     sc = scenes.heightfield(n_lights=1)
     r = pkg.Renderer(0); r.upload(sc["meshes"], sc["lights"], sc["materials"]); r.set_camera(sc["camera"]["position"], sc["camera"]["matrix"]); r.change_shading_mode(a.mode)
+    for o in a.set: r.set_option(o.split("=")[0], int(o.split("=")[1]))
     W, H = 1920, 1080
     ref = None
     for N in [int(v) for v in a.ranks.split(",")]:
