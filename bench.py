@@ -323,30 +323,54 @@ def main():
                 r.render_frame_device(W, H, frames[k].data_ptr())
                 state["last"] = frames[k]
         else:
-            # one contiguous staging / gathered buffer per launch slot: a batch travels in ONE all-gather ([rank][frame][slot])
-            staging = [torch.zeros(batch * per, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
-            gathered = [torch.zeros(world * batch * per, dtype=torch.int32, device="cuda") for _ in range(n_fly)]
-            out = [[torch.zeros(W * H, dtype=torch.int32, device="cuda") for _ in range(batch)] for _ in range(n_fly)]
+            # one contiguous staging / gathered buffer per launch slot: a batch travels in ONE all-gather ([rank][frame][slot]).
+            # With one launch in flight (the policy of `value`) the frame-end exchange -- all-gather + de-interleave -- runs on a
+            # communication stream of its own with double buffers, so frame f's tiles travel while frame f + 1 renders: the render
+            # launches still run strictly one after the other, the collective overlaps compute
+            overlap = n_fly == 1
+            slots = 2 if overlap else n_fly
+            comm = torch.cuda.Stream() if overlap else None
+            if overlap:
+                streams.append(comm)
+            staging = [torch.zeros(batch * per, dtype=torch.int32, device="cuda") for _ in range(slots)]
+            gathered = [torch.zeros(world * batch * per, dtype=torch.int32, device="cuda") for _ in range(slots)]
+            out = [[torch.zeros(W * H, dtype=torch.int32, device="cuda") for _ in range(batch)] for _ in range(slots)]
+            exchanged = [None] * slots  # event: the exchange that last read staging[k] / wrote out[k] is done
 
             def step(i):
                 # frames i, i+1, ... of one batch are issued when its first frame is due; the others are already covered
                 if i % batch:
                     return
                 nb = min(batch, state["total"] - i)
-                k = state["launches"] % n_fly
+                k = state["launches"] % slots
                 state["launches"] += 1
-                r.set_stream(streams[k].cuda_stream)
-                with torch.cuda.stream(streams[k]):
+                rs = streams[0] if overlap else streams[k]   # render stream
+                xs = comm if overlap else streams[k]         # exchange stream
+                r.set_stream(rs.cuda_stream)
+                if overlap and exchanged[k] is not None:
+                    rs.wait_event(exchanged[k])              # the buffers of two frames ago are free again
+                with torch.cuda.stream(rs):
                     r.render_tiles_batch_device(W, H, rank, world, [staging[k].data_ptr() + 4 * per * f for f in range(nb)])
+                if overlap:
+                    rendered = torch.cuda.Event()
+                    rendered.record(rs)
+                    xs.wait_event(rendered)
+                    r.set_stream(xs.cuda_stream)             # (the de-interleave kernel goes where the collective goes)
+                with torch.cuda.stream(xs):
                     if state["time_gather"]:
                         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                        e0.record(streams[k])
+                        e0.record(xs)
                     host.gather_batch(staging[k][:nb * per], W, H, nb,
                                       lambda g, f, k=k, nb=nb: (r.untile_batch_device(W, H, world, nb, f, g.data_ptr(), out[k][f].data_ptr()), out[k][f])[1],
                                       gathered[k][:world * nb * per])
                     if state["time_gather"]:
-                        e1.record(streams[k])
+                        e1.record(xs)
                         state["gather_ev"].append((e0, e1))
+                    if overlap:
+                        exchanged[k] = torch.cuda.Event()
+                        exchanged[k].record(xs)
+                if overlap:
+                    r.set_stream(rs.cuda_stream)
                 state["last"] = out[k][nb - 1]
         return step, state, streams
 
@@ -361,19 +385,20 @@ def main():
             i += 1
         torch.cuda.synchronize()
         extra = 0
-        while (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms and extra < 4096:
+        while extra < 4096:
+            # every rank issues the same number of steps (they contain collectives): rank 0's clock decides, chunk by chunk
+            go = (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms
+            if multi:
+                flag = torch.tensor([1 if go else 0], dtype=torch.int32, device="cuda")
+                dist.broadcast(flag, src=0)
+                go = bool(flag.item())
+            if not go:
+                break
             for _ in range(8):
                 step(i)
                 i += 1
             extra += 8
             torch.cuda.synchronize()
-        if multi:  # every rank issues the same number of collectives: take the largest spin-up count
-            n_extra = torch.tensor([extra], dtype=torch.int64, device="cuda")
-            dist.all_reduce(n_extra, op=dist.ReduceOp.MAX)
-            while extra < int(n_extra.item()):
-                step(i)
-                i += 1
-                extra += 1
         fence()
         state["total"] = steps
         state["launches"] = 0
@@ -491,7 +516,8 @@ def main():
                        "frames_in_flight": n_fly * batch, "launches_in_flight": n_fly, "frames_per_launch": batch,
                        "untimed_steps_before_the_timed_region": untimed_steps,
                        "camera": "static" + ("" if path else " (launch order of the unchanged view settled before the timed region); moving camera: moving_camera_ms_per_frame"),
-                       "parallelism": "1 GPU, one launch per frame" if world == 1 else "framebuffer tiles 16x16 round-robin over %d GPUs + 1 RCCL all-gather/frame" % world,
+                       "parallelism": "1 GPU, one launch per frame" if world == 1 else "framebuffer tiles 16x16 round-robin over %d GPUs + 1 RCCL all-gather/frame "
+                                      "(the all-gather and the de-interleave of frame f run on a communication stream beside frame f + 1's render)" % world,
                        "bvh": {"nodes": r.bvh_info()["n_nodes"], "max_depth": r.bvh_info()["max_depth"], "build_and_upload_s": upload_s}},
             "ms_per_frame": ms_per_step,
             "stream_ms_per_step": stream_ms / args.steps,
