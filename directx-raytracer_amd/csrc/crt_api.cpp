@@ -78,6 +78,7 @@ struct crt_ctx {
     uint32_t pathSpp = 4, pathBounces = 3, pathSeed = 1234; // mode 200 (BASELINE.json configs[4]: 4 spp, 3 bounces)
     uint32_t phongKsPermille = 0, phongExp = 32;            // mode 100: specular term, off by default
     uint32_t tunePathTile = 0;     // mode 200 work split: 0 = default (8), 8 / 16 = pixel tile edge per workgroup
+    uint32_t tunePathRanges = 8;   // mode 200: 8 = every XCD works through its own contiguous part of the frame first, 1 = one shared work counter
     // wave scheduling threshold of the closest-hit traversal loop (traversal.hip.h closestIteration; an int: > 0 = node steps while
     // that many lanes stand on inner nodes, -k = while k eighths of the wavefront's LIVE lanes do) and of the any-hit loop.
     // -6 against round 2's fixed 32: primary rays only 0.193 -> 0.172 ms, icosphere soup 0.256 -> 0.231, 5M triangles 0.367 -> 0.352,
@@ -311,7 +312,8 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         p.path_samples = std::min<uint32_t>(p.path_tile == 16u ? 4u : 16u, std::max<uint32_t>(1u, p.spp));
         p.path_region_bytes = crt::pathRegionBytes(p.path_tile, p.path_samples);
         p.path_work_items = crt::pathWorkgroupCount(p);
-        const size_t kHead = 256; // the work counter lives in front of the regions
+        const size_t kHead = 512; // the work counters (one 64-byte line per range) live in front of the regions
+        p.path_ranges = c->tunePathRanges;
         const size_t need = kHead + static_cast<size_t>(crt::pathGridSize(p)) * p.path_region_bytes;
         // the arena this stream used last; else an unused one; else the least recently used one of another stream
         for (auto& a : c->pathArena)
@@ -335,7 +337,7 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         arena->serial = c->frameSerial;
         p.path_counter = reinterpret_cast<uint32_t*>(arena->mem);
         p.path_scratch = arena->mem + kHead;
-        HIP_TRY(c, hipMemsetAsync(p.path_counter, 0, sizeof(uint32_t), c->stream));
+        HIP_TRY(c, hipMemsetAsync(p.path_counter, 0, kHead, c->stream));
     }
     // Cost feedback: the lifetimes frame f's wavefronts report are sorted on a side stream while the next frames render and
     // order the launch of frame f + kRing (same ring slot), so neither the sort nor the dependency on an earlier frame
@@ -800,6 +802,10 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
     }
     if (std::strcmp(name, "seed") == 0) {
         c->pathSeed = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "path_ranges") == 0 && (value == 1 || value == 8)) {
+        c->tunePathRanges = static_cast<uint32_t>(value);
         return CRT_OK;
     }
     if (std::strcmp(name, "path_tile") == 0 && (value == 0 || value == 8 || value == 16)) {

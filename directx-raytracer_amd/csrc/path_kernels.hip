@@ -23,6 +23,7 @@ namespace {
 // updates, their order -- is the oracle's, so frames stay bit-exact; the sample average runs in sample order at the end.
 // Samples beyond `path_samples` are further passes of the same wavefront over the same scratch.
 constexpr uint32_t kShadePlanes = 3, kTracePlanes = 2;
+constexpr uint32_t kPathCounterStride = 16; // dwords between the work counters of two ranges (one 64-byte line each)
 
 struct PathScratch {
     float4* shade;   // kShadePlanes x B: {o, rng} {d, id | bounce << 16} {t, u, v, tri}
@@ -299,11 +300,33 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
         q.accum = q.thr + q.B;
     }
     const F3 miss = f3(p.miss[0], p.miss[1], p.miss[2]);
+#if CRT_PROF // diagnostic build: cycles and lane use of the three stages (0 = A camera rays, 1 = B shade + shadow rays, 2 = C bounce rays)
+    unsigned long long pT[3] = { 0, 0, 0 }, pTN[3] = { 0, 0, 0 }, pTL[3] = { 0, 0, 0 };
+    uint32_t pIN[3] = { 0, 0, 0 }, pIL[3] = { 0, 0, 0 }, pLN[3] = { 0, 0, 0 }, pLL[3] = { 0, 0, 0 };
+    unsigned long long pT0 = 0;
+    const unsigned long long pK0 = __builtin_amdgcn_s_memtime();
+#define CRT_PATH_PROF_BEGIN() { stack.tNode = stack.tLeaf = 0; stack.itNode = stack.itLeaf = stack.lanesNode = stack.lanesLeaf = 0; pT0 = __builtin_amdgcn_s_memtime(); }
+#define CRT_PATH_PROF_END(S) { pT[S] += __builtin_amdgcn_s_memtime() - pT0; pTN[S] += stack.tNode; pTL[S] += stack.tLeaf; pIN[S] += stack.itNode; pIL[S] += stack.itLeaf; pLN[S] += stack.lanesNode; pLL[S] += stack.lanesLeaf; }
+#else
+#define CRT_PATH_PROF_BEGIN()
+#define CRT_PATH_PROF_END(S)
+#endif
+    // XCD affinity: the work items (which walk the frame in 4x4 blocks of tiles) are cut into p.path_ranges contiguous ranges, one
+    // counter each.  A wavefront works through the range of the XCD it runs on (HW_REG_XCC_ID), so the XCD's own L2 keeps
+    // serving one part of the frame and of the scene; when that range is used up it goes on with the next XCD's (stealing).
+    const uint32_t nRanges = p.path_ranges;
+    const uint32_t rangeLen = (nWork + nRanges - 1u) / nRanges;
+    uint32_t range = nRanges > 1u ? (__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu) % nRanges : 0u; // HW_REG_XCC_ID[3:0]
+    uint32_t tried = 0;
   for (;;) {
     uint32_t item = 0;
-    if (lane == 0) item = atomicAdd(p.path_counter, 1u);
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= nWork) break;
+    if (lane == 0) item = atomicAdd(p.path_counter + range * kPathCounterStride, 1u);
+    item = __builtin_amdgcn_readfirstlane(item) + range * rangeLen;
+    if (item >= min(nWork, (range + 1u) * rangeLen)) { // this range is used up (every wavefront gets here: the counters only grow)
+        if (++tried >= nRanges) break;
+        range = range + 1u == nRanges ? 0u : range + 1u;
+        continue;
+    }
     iters = 0; // the raised issue priority of a long tile (kBoostAfter) ends with it
     __builtin_amdgcn_s_setprio(0);
     const uint32_t frame = p.n_batch > 1u ? item % p.n_batch : 0u;
@@ -332,6 +355,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
     for (uint32_t s0 = 0; s0 < p.spp; s0 += p.path_samples) {
         const uint32_t nS = min(p.path_samples, p.spp - s0);
         uint32_t nShade = 0; // wave-uniform queue lengths
+        CRT_PATH_PROF_BEGIN()
         // ---- stage A: the tile's camera rays, one 8x8 packet of one sample at a time
         for (uint32_t sl = 0; sl < nS; sl++) {
             for (uint32_t sb = 0; sb < subCount; sb++) {
@@ -379,11 +403,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
             }
         }
         // ---- stages B / C until no path is left
+        CRT_PATH_PROF_END(0)
         while (nShade != 0u) {
             uint32_t nTrace = 0;
+            CRT_PATH_PROF_BEGIN()
             streamShade<COUNT, L>(p, nodes, tris, q, nShade, nTrace, stack, static_cast<int>(p.tune_inner_min_any), iters, cntNodes, cntTris, cntShadow); // stage B
+            CRT_PATH_PROF_END(1)
             nShade = 0;
+            CRT_PATH_PROF_BEGIN()
             streamClosest<COUNT, L>(nodes, tris, p.n_nodes, q, nTrace, nShade, miss, stack, innerMin, iters, cntNodes, cntTris, cntClosest); // stage C
+            CRT_PATH_PROF_END(2)
         }
         // ---- this pass's samples join the running sums in sample order; after the last pass: average, quantise, store
         const bool last = s0 + nS >= p.spp;
@@ -421,6 +450,17 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
         }
     }
   } // next work item
+#if CRT_PROF
+    if (COUNT && lane == 0) { // counters[4] = wave lifetime, then 7 words per stage: cycles, in node steps, in leaf steps, node / leaf phases, lanes in them
+        atomicAdd(&p.counters[4], __builtin_amdgcn_s_memtime() - pK0);
+        for (int st = 0; st < 3; st++) {
+            unsigned long long* c = p.counters + 5 + 7 * st;
+            atomicAdd(&c[0], pT[st]); atomicAdd(&c[1], pTN[st]); atomicAdd(&c[2], pTL[st]);
+            atomicAdd(&c[3], static_cast<unsigned long long>(pIN[st])); atomicAdd(&c[4], static_cast<unsigned long long>(pIL[st]));
+            atomicAdd(&c[5], static_cast<unsigned long long>(pLN[st])); atomicAdd(&c[6], static_cast<unsigned long long>(pLL[st]));
+        }
+    }
+#endif
     if (COUNT) {
         const uint32_t a = waveSum(cntNodes), c = waveSum(cntTris), sh = waveSum(cntShadow), cl = waveSum(cntClosest);
         if (lane == 0) {

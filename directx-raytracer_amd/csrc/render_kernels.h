@@ -71,6 +71,7 @@ struct RenderParams {
     unsigned char* path_scratch;  // pathGridSize() regions of path_region_bytes: one per RESIDENT workgroup of the persistent kernel
     uint32_t* path_counter;       // work-item counter of the launch (zeroed on the stream before it)
     uint32_t path_work_items;     // pathWorkgroupCount(): pixel tiles x frames of the batch
+    uint32_t path_ranges;         // 1 or 8: contiguous ranges of the work items, one counter (64 bytes apart) and one home XCD each
     size_t path_region_bytes;     // pathRegionBytes(path_samples)
     uint32_t path_tile;           // 16: one workgroup per 16x16 macro tile; 8: one per 8x8 packet
     uint32_t path_samples;        // samples of the tile carried through the pipeline together: B = tile^2 x this paths (<= 1024)

@@ -547,9 +547,11 @@ def test_path_tracing_cornell_all_material_types(pkg, oracle, scenes, renderer):
     try:
         _compare_path(pkg, oracle, renderer, sc, 70, 50, 37, 2, 99)              # passes of 16 + 16 + 5
         renderer.set_option("path_tile", 16)
+        renderer.set_option("path_ranges", 1)                                    # one shared work counter instead of one per XCD
         _compare_path(pkg, oracle, renderer, sc, 70, 50, 9, 2, 5)                # passes of 4 + 4 + 1, macro-tile workgroups
     finally:
         renderer.set_option("path_tile", 0)
+        renderer.set_option("path_ranges", 8)
 
 
 def test_path_tracing_dragon_smooth_normals_and_mirror_ground(pkg, oracle, scenes, dragon, renderer):
@@ -1022,6 +1024,61 @@ def test_frames_in_flight_and_launch_order_feedback(pkg, oracle, scenes, dragon,
         torch.cuda.synchronize()
         renderer.set_option("adaptive_order", 2)
         renderer.reset_stream()
+
+
+def test_path_frames_in_flight_share_scratch_safely(pkg, oracle, scenes, renderer):
+    """Mode 200 frames issued back to back: on ONE stream they reuse one scratch arena and one work counter in stream order;
+    on more streams than there are arenas an arena is taken over from the least recently used stream behind an event.
+    Every frame, rendered into its own sentinel-filled buffer, must be the oracle's frame.  The arena is sized by the
+    workgroups RESIDENT on the device, not by the frame: a 4K frame at 16 spp must not grow device memory by more than
+    the documented bound (608 MB per stream at 16 samples -- the frame-sized scratch it replaced was 15 GB)."""
+    import torch
+    sc = scenes.cornell_box()
+    sc["materials"][1] = {"albedo": (0.9, 0.9, 0.9), "type": 2}
+    cam = sc["camera"]
+    renderer.upload(sc["meshes"], sc["lights"], sc["materials"])
+    renderer.set_camera(cam["position"], cam["matrix"])
+    renderer.change_shading_mode(pkg.MODE_PATH)
+    renderer.set_path_params(2, 2, 4321)
+    oracle.set_path_params(2, 2, 4321)
+    O = oracle.OracleScene(sc["meshes"], sc["lights"], sc["materials"])
+    streams = [torch.cuda.Stream() for _ in range(6)]
+    try:
+        refs = {}
+        n = 0
+        for n_streams in (1, 6, 2):
+            for (w, h), frames in (((160, 120), 9), ((97, 61), 7), ((160, 120), 8)):
+                if (w, h) not in refs:
+                    refs[(w, h)] = O.render(cam["position"], cam["matrix"], oracle.MODE_PATH, w, h)["rgba8"].reshape(-1, 4).copy().view(np.uint32).ravel()
+                bufs = [torch.full((w * h,), 0x7E57AB1E, dtype=torch.int32, device="cuda") for _ in range(frames)]
+                torch.cuda.synchronize()
+                for b in bufs:
+                    renderer.set_stream(streams[n % n_streams].cuda_stream)
+                    n += 1
+                    renderer.render_frame_device(w, h, b.data_ptr())
+                torch.cuda.synchronize()
+                for i, b in enumerate(bufs):
+                    got = b.cpu().numpy().view(np.uint32)
+                    assert np.array_equal(got, refs[(w, h)]), "%d streams, %dx%d frame %d: %d pixels differ" % (
+                        n_streams, w, h, i, int((got != refs[(w, h)]).sum()))
+        # scratch bound: 4K, 16 samples per pixel, frames on one stream
+        renderer.set_stream(streams[0].cuda_stream)
+        renderer.set_path_params(16, 3, 1)
+        frame = torch.zeros(3840 * 2160, dtype=torch.int32, device="cuda")
+        renderer.render_frame_device(256, 256, frame.data_ptr())
+        torch.cuda.synchronize()
+        free0 = torch.cuda.mem_get_info()[0]
+        for _ in range(3):
+            renderer.render_frame_device(3840, 2160, frame.data_ptr())
+        torch.cuda.synchronize()
+        grown = free0 - torch.cuda.mem_get_info()[0]
+        assert grown < 768 * 2**20, "a 4K / 16 spp path frame grew device memory by %.0f MB" % (grown / 2**20)
+    finally:
+        torch.cuda.synchronize()
+        oracle.set_path_params(4, 3, 1234)
+        renderer.set_path_params(4, 3, 1234)
+        renderer.reset_stream()
+        renderer.change_shading_mode(0)
 
 
 def test_batch_launch_equals_single_frames(pkg, oracle, scenes, dragon, renderer):

@@ -46,7 +46,11 @@ def main():
             med[k] = {"median": statistics.median(v), "min": min(v), "max": max(v), "launches": len(v)}
     out = {"kernel": kernel + "...>", "workload": key, "dispatch": meta, "counters": med}
     m = lambda k: med[k]["median"] if k in med else None
-    inputs = {"from": "profiles/%s_pmc.json" % tag, "kernel_source_hash": bench.kernel_source_hash()}
+    # the hash written on the GPU box beside the counters; a profile directory from before that was recorded is taken to belong to
+    # the working tree (parse it before editing the kernels)
+    hash_file = os.path.join(src, "kernel_source_hash.txt")
+    src_hash = open(hash_file).read().strip() if os.path.exists(hash_file) else bench.kernel_source_hash()
+    inputs = {"from": "profiles/%s_pmc.json" % tag, "kernel_source_hash": src_hash}
     try:
         inputs["commit"] = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
     except Exception:

@@ -23,13 +23,12 @@ def main():
         rays = c["rays_primary"] + c["rays_shadow"]
         for tile in ([0] if "--sweep" not in sys.argv else [8, 16]):
             for im in ([32] if "--sweep" not in sys.argv else [16, 32, 48]):
-                r.set_option("path_tile", tile)
-                if "--sweep" in sys.argv: r.set_option("inner_min", im)
+                if "--sweep" in sys.argv: r.set_option("path_tile", tile); r.set_option("inner_min", im)
                 for _ in range(2): r.render_frame_device(W, H, frame.data_ptr(), stats=True)
                 ms = statistics.median([r.render_frame_device(W, H, frame.data_ptr(), stats=True)["kernel_ms"] for _ in range(7)])
                 print("%s mode 200 4 spp 3 bounces (path_tile %d, inner_min %d): %.3f ms/frame  rays %d (closest %d, shadow %d)  %.0f Mray/s  nodes/ray %.1f tris/ray %.1f" % (
                     name, tile, im, ms, rays, c["rays_primary"], c["rays_shadow"], rays / ms / 1e3, c["nodes_visited"] / rays, c["tris_tested"] / rays), flush=True)
-        r.set_option("path_tile", 0)
+        if "--sweep" in sys.argv: r.set_option("path_tile", 0)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,29 @@
+#!/usr/bin/env python3
+"""Mode 200 (C5: 5M triangles, 4K, 4 spp, 3 bounces) over a grid of two options: tools/path_sweep.py nameA=v1,v2,.. nameB=v1,v2,.. [fixed=val ...]"""
+
+
+def main():
+    import importlib, itertools, os, statistics, sys
+    ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+    import __graft_entry__ as e
+    import torch
+    pkg = e.load_package(); scenes = importlib.import_module(e.PKG_NAME + ".scenes")
+    if os.environ.get("CRT_LIB"): pkg.LIB_PATH = os.path.abspath(os.environ["CRT_LIB"])
+    small = "--c3" in sys.argv
+    sc = scenes.heightfield(n_lights=1) if small else scenes.heightfield(n=1581, n_lights=1)
+    W, H = (1920, 1080) if small else (3840, 2160)
+    r = pkg.Renderer(0)
+    r.upload(sc["meshes"], sc["lights"], sc["materials"]); r.set_camera(sc["camera"]["position"], sc["camera"]["matrix"])
+    r.change_shading_mode(pkg.MODE_PATH); r.set_path_params(4, 3, 1234)
+    frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    grid = [(a.split("=")[0], [int(v) for v in a.split("=")[1].split(",")]) for a in sys.argv[1:] if "=" in a]
+    names = [g[0] for g in grid]
+    for combo in itertools.product(*[g[1] for g in grid]):
+        for n, v in zip(names, combo): r.set_option(n, v)
+        for _ in range(2): r.render_frame_device(W, H, frame.data_ptr(), stats=True)
+        ms = statistics.median([r.render_frame_device(W, H, frame.data_ptr(), stats=True)["kernel_ms"] for _ in range(5)])
+        print("  ".join("%s=%d" % nv for nv in zip(names, combo)), "-> %.3f ms" % ms, flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,28 @@ def main():
     r = pkg.Renderer(0); r.upload(sc["meshes"], sc["lights"], sc["materials"]); r.set_camera(sc["camera"]["position"], sc["camera"]["matrix"])
     W, H = 1920, 1080
     frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+    if "--path" in sys.argv:  # mode 200: the three stages of the path kernel; name=value arguments are options (path_pipeline=1 ...)
+        big = "--c5" in sys.argv
+        if big:
+            sc = scenes.heightfield(n=1581, n_lights=1); W, H = 3840, 2160
+            r.upload(sc["meshes"], sc["lights"], sc["materials"]); r.set_camera(sc["camera"]["position"], sc["camera"]["matrix"])
+            frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
+        for o in [x for x in sys.argv[1:] if "=" in x]: r.set_option(o.split("=")[0], int(o.split("=")[1]))
+        r.change_shading_mode(pkg.MODE_PATH); r.set_path_params(4, 3, 1234)
+        for _ in range(2): r.render_frame_device(W, H, frame.data_ptr(), stats=True)
+        r.set_counting(True)
+        st = r.render_frame_device(W, H, frame.data_ptr(), stats=True)
+        c = r.read_counters().astype(np.float64)
+        r.set_counting(False)
+        print("mode 200 %dx%d: kernel %.3f ms (instrumented); rays closest %d shadow %d" % (W, H, st["kernel_ms"], c[3], c[2]))
+        life = c[4]
+        for i, name in enumerate(("A camera rays", "B shade + shadow rays" , "C bounce rays")):
+            t, tn, tl, itn, itl, lan, lal = c[5 + 7 * i: 12 + 7 * i]
+            if t == 0: continue
+            print("  stage %-22s %5.1f%% of the wavefronts' life: node steps %4.1f%%  leaf steps %4.1f%%  rest %4.1f%%" % (name, 100 * t / life, 100 * tn / t, 100 * tl / t, 100 * (t - tn - tl) / t))
+            if itn and itl:
+                print("      node phases %d (%.0f cycles, %.1f lanes)   leaf phases %d (%.0f cycles, %.1f lanes)" % (itn, tn / itn, lan / itn, itl, tl / itl, lal / itl))
+        return
     for mode in (3, 100):
         r.change_shading_mode(mode)
         for _ in range(4): r.render_frame_device(W, H, frame.data_ptr(), stats=True)

@@ -15,6 +15,8 @@ B="python3 $ROOT/bench.py --config $CONFIG --no-cpu-baseline --no-extras"
 if [ -n "$SCENE" ]; then B="$B --scene $SCENE"; fi
 STEPS=50; PSTEPS=8
 if [ "$CONFIG" = "c5" ]; then STEPS=10; PSTEPS=3; fi
+# the sources these counters belong to, recorded where and when they are measured (parse_profile.py copies it into roofline_inputs.json)
+(cd $ROOT && python3 -c "import bench; print(bench.kernel_source_hash())") > $OUT/kernel_source_hash.txt
 timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B --steps $STEPS --warmup 5 > $OUT/bench_trace.log 2>&1
 echo "trace done"
 i=0
