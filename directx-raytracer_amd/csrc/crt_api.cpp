@@ -78,6 +78,8 @@ struct crt_ctx {
     uint32_t pathSpp = 4, pathBounces = 3, pathSeed = 1234; // mode 200 (BASELINE.json configs[4]: 4 spp, 3 bounces)
     uint32_t phongKsPermille = 0, phongExp = 32;            // mode 100: specular term, off by default
     uint32_t tunePathTile = 0;     // mode 200 work split: 0 = default (8), 8 / 16 = pixel tile edge per workgroup
+    uint32_t tunePathPipeline = 0; // mode 200: 0 = one persistent kernel with wavefront-private queues (default: 21.2 vs 23.4 ms on C5), 1 = the stages as separate launches over global queues
+    uint32_t tunePathPassPaths = 1u << 24; // wavefront pipeline: paths one pass may carry (112 bytes of queue / radiance memory each)
     uint32_t tunePathRanges = 8;   // mode 200: 8 = every XCD works through its own contiguous part of the frame first, 1 = one shared work counter
     // wave scheduling threshold of the closest-hit traversal loop (traversal.hip.h closestIteration; an int: > 0 = node steps while
     // that many lanes stand on inner nodes, -k = while k eighths of the wavefront's LIVE lanes do) and of the any-hit loop.
@@ -288,7 +290,11 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         const uint32_t deepest = c->bvh.width ? (c->bvh.width - 1u) * c->bvh.depthWide + 1u : 3u * c->bvh.depth4 + 1u;
         p.spill_stride = deepest > p.stack_entries ? deepest - p.stack_entries : 1u;
         // (mode 200: one slice per resident workgroup of the persistent kernel)
-        if (p.mode >= 200u) p.path_tile = c->tunePathTile ? c->tunePathTile : 8u;
+        if (p.mode >= 200u) {
+            p.path_tile = c->tunePathTile ? c->tunePathTile : 8u;
+            // the stages as separate launches over global queues (8x8 work items, 64-byte nodes), or one persistent kernel
+            p.path_wavefront = (c->tunePathPipeline == 1u && p.path_tile == 8u && c->bvh.width == 0u) ? 1u : 0u;
+        }
         // (+ 64 slices for each of the four wavefronts of a split packet)
         const size_t groups = p.mode >= 200u ? static_cast<size_t>(crt::pathGridSize(p))
                                              : (static_cast<size_t>(crt::renderUnitCount(p)) + 16u * std::min(c->tuneSplitUnits == crt_ctx::kSplitAuto ? 128u : c->tuneSplitUnits, crt::renderUnitCount(p) / 4u)) * p.n_batch;
@@ -314,7 +320,13 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         p.path_work_items = crt::pathWorkgroupCount(p);
         const size_t kHead = 512; // the work counters (one 64-byte line per range) live in front of the regions
         p.path_ranges = c->tunePathRanges;
-        const size_t need = kHead + static_cast<size_t>(crt::pathGridSize(p)) * p.path_region_bytes;
+        uint32_t wfItems = 0;
+        if (p.path_wavefront) {
+            wfItems = crt::pathWavefrontPassItems(p, c->tunePathPassPaths);
+            p.wf_paths = wfItems * 64u * p.path_samples;
+            crt::pathWavefrontLayout(p, wfItems, p.wf_chunk, p.wf_stride);
+        }
+        const size_t need = p.path_wavefront ? crt::pathWavefrontBytes(p, wfItems) : kHead + static_cast<size_t>(crt::pathGridSize(p)) * p.path_region_bytes;
         // the arena this stream used last; else an unused one; else the least recently used one of another stream
         for (auto& a : c->pathArena)
             if (a.used && a.stream == c->stream) arena = &a;
@@ -335,9 +347,20 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         }
         if (!arena->lastUse) HIP_TRY(c, hipEventCreateWithFlags(&arena->lastUse, hipEventDisableTiming));
         arena->serial = c->frameSerial;
-        p.path_counter = reinterpret_cast<uint32_t*>(arena->mem);
-        p.path_scratch = arena->mem + kHead;
-        HIP_TRY(c, hipMemsetAsync(p.path_counter, 0, kHead, c->stream));
+        if (p.path_wavefront) {
+            const size_t plane = static_cast<size_t>(p.wf_paths) * 16u, qplane = static_cast<size_t>(p.wf_stride) * 16u; // one float4 per path / queue entry
+            unsigned char* at = arena->mem;
+            p.wf_counts = reinterpret_cast<uint32_t*>(at); at += crt::kWfHeadBytes;
+            p.wf_shade_q = at; at += 3u * qplane;
+            p.wf_trace_q = at; at += 2u * qplane;
+            p.wf_done = at; at += plane;
+            p.wf_thr = at; at += plane;
+            p.wf_accum = p.spp > p.path_samples ? at : nullptr;
+        } else {
+            p.path_counter = reinterpret_cast<uint32_t*>(arena->mem);
+            p.path_scratch = arena->mem + kHead;
+            HIP_TRY(c, hipMemsetAsync(p.path_counter, 0, kHead, c->stream));
+        }
     }
     // Cost feedback: the lifetimes frame f's wavefronts report are sorted on a side stream while the next frames render and
     // order the launch of frame f + kRing (same ring slot), so neither the sort nor the dependency on an earlier frame
@@ -802,6 +825,14 @@ int crt_set_option(crt_ctx* c, const char* name, int value)
     }
     if (std::strcmp(name, "seed") == 0) {
         c->pathSeed = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "path_pipeline") == 0 && (value == 0 || value == 1)) {
+        c->tunePathPipeline = static_cast<uint32_t>(value);
+        return CRT_OK;
+    }
+    if (std::strcmp(name, "path_pass_paths") == 0 && value >= (1 << 16) && value <= (1 << 25)) {
+        c->tunePathPassPaths = static_cast<uint32_t>(value);
         return CRT_OK;
     }
     if (std::strcmp(name, "path_ranges") == 0 && (value == 1 || value == 8)) {

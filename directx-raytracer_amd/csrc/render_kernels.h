@@ -75,6 +75,19 @@ struct RenderParams {
     size_t path_region_bytes;     // pathRegionBytes(path_samples)
     uint32_t path_tile;           // 16: one workgroup per 16x16 macro tile; 8: one per 8x8 packet
     uint32_t path_samples;        // samples of the tile carried through the pipeline together: B = tile^2 x this paths (<= 1024)
+    // mode 200, wavefront pipeline (path_pipeline 1): the stages as separate launches over global queues (path_kernels.hip)
+    uint32_t path_wavefront;      // 1: launchPath runs the wavefront pipeline
+    void* wf_shade_q;             // float4 arrays.  3 planes x wf_paths: {o, rng} {d, id | bounce << 25} {t, u, v, tri}
+    void* wf_trace_q;         // 2 planes x wf_paths
+    void* wf_done;            // wf_paths: a path's radiance so far
+    void* wf_thr;             // wf_paths: its throughput
+    void* wf_accum;           // nullable: 64 per work item of a pass, sums of earlier passes (spp > path_samples)
+    uint32_t* wf_counts;          // kWfHeadBytes: work counters of the camera launch, then {length, cursor} per queue
+    uint32_t wf_paths;            // capacity of a pass in paths = plane stride (pathWavefrontPassItems() x 64 x path_samples)
+    uint32_t wf_stride, wf_chunk; // the queues' capacity in entries (= plane stride) and the entries a wavefront reserves per atomic (pathWavefrontLayout)
+    uint32_t wf_item0, wf_items;  // the work items of this pass
+    uint32_t wf_queue;            // queue a shade / trace launch consumes (it fills wf_queue + 1)
+    uint32_t wf_s0;               // first sample of this pass
     unsigned long long* timeline; // counting variant only, nullable: per workgroup {start, end} of s_memrealtime (100 MHz) + XCC id
 };
 
@@ -87,6 +100,12 @@ int launchPath(const RenderParams& p, bool counting, ihipStream_t* stream);
 // mode 200 scratch sizing
 size_t pathRegionBytes(uint32_t tile, uint32_t samples_per_pass);
 uint32_t pathWorkgroupCount(const RenderParams& p);
+// wavefront pipeline: bytes in front of the queues (counters), work items one pass may carry for a budget of paths, and the
+// arena a pass of `items` work items needs
+constexpr size_t kWfHeadBytes = 4096;
+uint32_t pathWavefrontPassItems(const RenderParams& p, uint32_t max_paths);
+void pathWavefrontLayout(const RenderParams& p, uint32_t items, uint32_t& chunk, uint32_t& stride);
+size_t pathWavefrontBytes(const RenderParams& p, uint32_t items);
 uint32_t pathGridSize(const RenderParams& p); // workgroups the persistent path kernel starts: min(work items, what the chip holds at once)
 // unit_cost -> unit_order (descending)
 int launchSortUnits(const uint32_t* cost, uint32_t* order, uint32_t n, bool xcdAffine, ihipStream_t* stream);

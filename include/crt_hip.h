@@ -226,7 +226,12 @@ int crt_render_frame_distributed(crt_ctx* ctx, uint32_t width, uint32_t height, 
  * split packet, default 4), "split_segments" (4, 8 or 16 pieces per split ray, default 16),
  * "xcd_affine_order" 0/1 (with a launch order: the frame is cut into eight regions of equal cost, one per XCD and its L2, each launched
  * most expensive packet first; default 0 -- primary rays alone gain 5 %, a shaded frame loses 1 %),
- * "path_tile" (mode 200 work split: pixel-tile edge per workgroup, 8 (default, also 0) or 16), "path_ranges" (mode 200: 8 (default) = the
+ * "path_tile" (mode 200 work split: pixel-tile edge per workgroup, 8 (default, also 0) or 16), "path_pipeline" (mode 200: 0 (default) = one persistent kernel
+ * whose wavefronts carry a pixel tile's paths through all stages with private queues; 1 = the stages as separate launches (camera rays,
+ * shade + shadow rays, bounce rays, resolve) over global queues: no register spills, 6-7 wavefronts per SIMD instead of 5, identical
+ * frames, 8 % slower on the 5M-triangle 4K frame because the compute-bound camera stage no longer overlaps the fetch-bound stream
+ * stages; its queues hold "path_pass_paths" paths per pass (65536..2^25, default 2^24 = 1.9 GB), a frame with more is rendered in
+ * several passes), "path_ranges" (mode 200: 8 (default) = the
  * work items are cut into eight contiguous ranges and a wavefront works through the range of the XCD it runs on before taking from the others', 1 = one shared work counter), "stack_entries" (0 = default 16; deeper entries spill to a
  * global arena). The diagnostic options "timeline", "debug_skip_units" and "debug_force_measure" (which do change what a frame
  * does) exist only in the diagnostic build of the library (tools/diag_build.sh); the product returns CRT_EINVAL for them. */

@@ -542,6 +542,18 @@ def test_path_tracing_cornell_all_material_types(pkg, oracle, scenes, renderer):
     got = _compare_path(pkg, oracle, renderer, sc, 200, 120, 3, 5, 42, miss=(0.2, 0.3, 0.4))
     assert np.isfinite(got["rgb"]).all()
     _compare_path(pkg, oracle, renderer, sc, 64, 64, 1, 0, 7)                    # no bounces at all
+    # the stages as separate launches over global queues (option path_pipeline = 1): same frames, same counters -- one pass, then
+    # passes of 64 work items each (64 x 64 x 3 paths), then more samples than a pass carries (16 + 16 + 5, cross-pass sums)
+    try:
+        renderer.set_option("path_pipeline", 1)
+        _compare_path(pkg, oracle, renderer, sc, 200, 120, 3, 5, 42, miss=(0.2, 0.3, 0.4))
+        renderer.set_option("path_pass_paths", 65536)
+        _compare_path(pkg, oracle, renderer, sc, 200, 120, 3, 5, 42, miss=(0.2, 0.3, 0.4))
+        _compare_path(pkg, oracle, renderer, sc, 70, 50, 37, 2, 99)
+        _compare_path(pkg, oracle, renderer, sc, 64, 64, 1, 0, 7)
+    finally:
+        renderer.set_option("path_pass_paths", 1 << 24)
+        renderer.set_option("path_pipeline", 0)
     # more samples than one pass of the pipeline carries (16 per 8x8 tile, 4 per 16x16 tile): the sample average must still run
     # in sample order across the passes (running sums kept in the workgroup's scratch)
     try:
@@ -1093,8 +1105,9 @@ def test_batch_launch_equals_single_frames(pkg, oracle, scenes, dragon, renderer
     w, h = 333, 217
     pos0 = np.float32(cam["position"])
     cams = [(pos0 + np.float32([0.7 * k, 0.1 * k, -0.4 * k]), scenes.camera_matrix(yaw_deg=4.0 * k, pitch_deg=-2.0 * k)) for k in range(4)]
-    for mode in (100, pkg.MODE_PATH):
+    for mode, pipeline in ((100, 0), (pkg.MODE_PATH, 0), (pkg.MODE_PATH, 1)):  # path tracing: persistent kernel, then stage launches
         renderer.change_shading_mode(mode)
+        renderer.set_option("path_pipeline", pipeline)
         refs = [O.render(p, r, mode, w, h)["rgba8"].reshape(-1, 4).copy().view(np.uint32).ravel() for p, r in cams]
         for n in (1, 2, 3, 4):
             bufs = [torch.full((w * h,), 0x7E57AB1E, dtype=torch.int32, device="cuda") for _ in range(n)]
@@ -1102,7 +1115,19 @@ def test_batch_launch_equals_single_frames(pkg, oracle, scenes, dragon, renderer
             st = renderer.render_frames_batch_device(w, h, [b.data_ptr() for b in bufs], cams[:n], stats=True)
             assert st["kernel_ms"] > 0
             for k, b in enumerate(bufs):
-                assert np.array_equal(b.cpu().numpy().view(np.uint32), refs[k]), "mode %d batch of %d, frame %d" % (mode, n, k)
+                assert np.array_equal(b.cpu().numpy().view(np.uint32), refs[k]), "mode %d pipeline %d batch of %d, frame %d" % (mode, pipeline, n, k)
+        if mode == pkg.MODE_PATH:  # a path-traced frame from three ranks' tile shares
+            renderer.set_camera(*cams[0])
+            slots3 = pkg.tile_slots(w, h, 3)
+            gathered3 = torch.zeros(3 * slots3 * 256, dtype=torch.int32, device="cuda")
+            out3 = torch.zeros(w * h, dtype=torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            for rank in range(3):
+                renderer.render_tiles_device(w, h, rank, 3, gathered3.data_ptr() + rank * slots3 * 1024, stats=True)
+            renderer.untile_device(w, h, 3, gathered3.data_ptr(), out3.data_ptr())
+            renderer.synchronize()
+            assert np.array_equal(out3.cpu().numpy().view(np.uint32), refs[0]), "path tracing, pipeline %d, three tile shares" % pipeline
+    renderer.set_option("path_pipeline", 0)
     # tile shares: batch == single-frame calls with the same cameras (n_ranks 3, every rank)
     renderer.change_shading_mode(100)
     slots = pkg.tile_slots(w, h, 3)
