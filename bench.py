@@ -12,10 +12,15 @@ every rank renders its tiles into a tile-major staging buffer, ONE RCCL all-gath
 de-interleave kernel rebuilds the row-major frame ("scaling": "strong": total work is fixed).
 value = rays traced by the whole job (primary + shadow, counted by the instrumented kernel variant) / wall time.
 
-Pipelining policy: `value` is measured with the SAME policy at every N -- one launch in flight, one frame per launch,
-frames issued back to back on one stream -- so the driver's 1 -> 8 curve compares like with like.  The throughput
-policy (4 launches in flight on alternating streams, and from 8 ranks up 2 frames per launch) is timed right after
-and reported as the labelled extra "pipelined"; it never replaces `value`.
+Pipelining policy.  N = 1: `value` is one launch in flight, one frame per launch, frames back to back on one stream (the
+roofline block needs the kernel's own launch duration over the timed region); the throughput policy (4 launches in flight
+on alternating streams) is timed right after and reported as the labelled extra "pipelined" (5 % faster).  N > 1: `value`
+is the throughput policy -- 4 launches in flight, from 8 ranks up 4 frames per launch -- because a rank's share of a
+1080p frame is tens of microseconds of work behind a tail of one grazing packet and a frame-end exchange, which only
+other frames' work can hide (one-GPU emulation, tools/dist_overhead.py: 8 ranks 121 us per frame with one launch in
+flight, 60 with four, 44 with four frames per launch: 6.5x one GPU's 285); the one-launch-in-flight figure is timed right
+after and reported as "one_launch_in_flight".  Every frame of the timed region is complete, gathered and de-interleaved
+on every rank before the closing barrier.  --inflight / --batch override both defaults.
 
 The CPU oracle (oracle/) is used here ONLY as the checker: the cpu_baseline leg (rank 0, N = 1, a bounded number of
 full frames) and the comparison of the last timed frame's RGBA8 with the frame that leg renders.
@@ -212,10 +217,13 @@ def main():
                          "(working set 650 MB > the 256 MB Infinity Cache: the HBM-regime data point)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the pipelined / moving-camera / D2H legs (profiling runs)")
-    ap.add_argument("--inflight", type=int, default=1, help="launches in flight for `value` (default 1 at every N: frames back to "
-                    "back on ONE stream, so the HIP events over the timed region measure the kernel's average launch duration and "
-                    "the rocprofv3 summary of the same command agrees with it)")
-    ap.add_argument("--batch", type=int, default=1, help="N>1 only: frames per launch (1..4) for `value`; default 1")
+    ap.add_argument("--inflight", type=int, default=0, help="launches in flight for `value`.  Default (0): 1 at N = 1 -- frames back to "
+                    "back on ONE stream, so the HIP events over the timed region measure the kernel's average launch duration and the "
+                    "rocprofv3 summary of the same command agrees with it; 4 at N > 1 -- a rank's share of a frame is a short launch "
+                    "whose tail and whose frame-end exchange only overlap with other frames' work")
+    ap.add_argument("--batch", type=int, default=0, help="N>1 only: frames per launch (1..4) for `value`.  Default (0): 1 below 8 ranks, "
+                    "4 from 8 ranks up (a 1/8 share of a 1080p frame is 37 us of work: one launch and one all-gather per frame "
+                    "are host-issue bound at 59 us, tools/dist_overhead.py)")
     ap.add_argument("--force-dist", action="store_true", help="run the N>1 code path (RCCL init, tile staging, all-gather, "
                     "de-interleave) with whatever world size the launcher gives, even 1")
     ap.add_argument("--check-dist-frame", action="store_true", help="N>1 path: compare the gathered frame with the oracle's even when "
@@ -420,8 +428,8 @@ def main():
             elapsed = float(tmax.item())
         return elapsed, stream_ms, warmup + extra
 
-    n_fly = max(1, args.inflight)
-    batch = max(1, min(4, args.batch)) if multi else 1
+    n_fly = args.inflight if args.inflight > 0 else (4 if multi else 1)
+    batch = (max(1, min(4, args.batch)) if args.batch > 0 else (4 if (world >= 8 and not path) else 1)) if multi else 1
     step, state, streams = policy(n_fly, batch)
     if n_fly == 1 and not path:
         # scene setup, like the BVH build: the launch order of an unchanged view settles after each of the library's 4 scratch
@@ -457,13 +465,16 @@ def main():
 
     extras = {}
     if not args.no_extras:
-        # throughput policy, labelled extra: 4 launches in flight on alternating streams; from 8 ranks up 2 frames per launch
-        p_fly, p_batch = 4, (2 if (multi and world >= 8) else 1)
+        # the OTHER policy, labelled extra, so that both are on record at every N: at N = 1 `value` is one launch in flight and this leg
+        # is the throughput policy (4 launches in flight on alternating streams); at N > 1 `value` is the throughput policy and this
+        # leg is one launch in flight, one frame per launch (frame f's exchange beside frame f + 1's render)
+        p_fly, p_batch = (1, 1) if multi else (4, 1)
         pstep, pstate, pstreams = policy(p_fly, p_batch)
         p_elapsed, _, _ = timed(pstep, pstate, pstreams, args.steps, max(args.warmup, 8))
-        extras["pipelined"] = {"launches_in_flight": p_fly, "frames_per_launch": p_batch, "ms_per_frame": p_elapsed / args.steps * 1e3,
-                               "value": rays_per_frame * args.steps / p_elapsed / 1e6, "unit": "Mray/s",
-                               "note": "throughput policy; `value` above uses 1 launch in flight, 1 frame per launch at every N"}
+        extras["one_launch_in_flight" if multi else "pipelined"] = {
+            "launches_in_flight": p_fly, "frames_per_launch": p_batch, "ms_per_frame": p_elapsed / args.steps * 1e3,
+            "value": rays_per_frame * args.steps / p_elapsed / 1e6, "unit": "Mray/s",
+            "note": "`value` above uses %d launch(es) in flight, %d frame(s) per launch" % (n_fly, batch)}
     if not args.no_extras and not multi and not path:
         # a camera that moves every frame (0.01 degrees of orbit: practically the same view, so the difference to the static
         # figure is the cost of measuring and sorting the launch order for every frame, as an interactive viewer pays it)
@@ -516,8 +527,8 @@ def main():
                        "frames_in_flight": n_fly * batch, "launches_in_flight": n_fly, "frames_per_launch": batch,
                        "untimed_steps_before_the_timed_region": untimed_steps,
                        "camera": "static" + ("" if path else " (launch order of the unchanged view settled before the timed region); moving camera: moving_camera_ms_per_frame"),
-                       "parallelism": "1 GPU, one launch per frame" if world == 1 else "framebuffer tiles 16x16 round-robin over %d GPUs + 1 RCCL all-gather/frame "
-                                      "(the all-gather and the de-interleave of frame f run on a communication stream beside frame f + 1's render)" % world,
+                       "parallelism": "1 GPU, one launch per frame" if world == 1 else "framebuffer tiles 16x16 round-robin over %d GPUs + 1 RCCL all-gather per launch; "
+                                      "%d launches in flight on alternating streams, %d frame(s) per launch (one_launch_in_flight: the same with 1 and 1)" % (world, n_fly, batch),
                        "bvh": {"nodes": r.bvh_info()["n_nodes"], "max_depth": r.bvh_info()["max_depth"], "build_and_upload_s": upload_s}},
             "ms_per_frame": ms_per_step,
             "stream_ms_per_step": stream_ms / args.steps,

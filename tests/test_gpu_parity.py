@@ -209,7 +209,7 @@ def test_c3_tiled_over_2_4_8_ranks_vs_oracle(pkg, oracle, scenes, renderer):
         renderer.untile_device(w, h, n, gathered.data_ptr(), frame.data_ptr())
         renderer.synchronize()
         np.testing.assert_array_equal(frame.cpu().numpy().view(np.uint32), ref, err_msg="n_ranks=%d" % n)
-        # batched variant (2 frames per launch, as bench.py's pipelined policy uses from 8 ranks up): same frames
+        # batched variant (several frames per launch, as bench.py does from 8 ranks up): same frames
         if n == 8:
             g2 = torch.zeros(n * 2 * slots * 256, dtype=torch.int32, device="cuda")
             torch.cuda.synchronize()
@@ -239,8 +239,8 @@ def test_rccl_gather_path_of_bench_in_a_fresh_process():
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
     assert line["frame_matches_oracle"] is True
-    assert line["config"]["launches_in_flight"] == 1 and line["config"]["frames_per_launch"] == 1
-    assert line["pipelined"]["launches_in_flight"] == 4 and line["pipelined"]["value"] > 0
+    assert line["config"]["launches_in_flight"] == 4 and line["config"]["frames_per_launch"] == 1  # the N > 1 default policy of `value`
+    assert line["one_launch_in_flight"]["launches_in_flight"] == 1 and line["one_launch_in_flight"]["value"] > 0
     assert line["rank0_render_kernel_ms"] > 0 and line["rank0_gather_untile_us"] > 0
     assert "all-gather" in line["config"]["parallelism"] or line["n_gpus"] == 1
 
