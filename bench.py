@@ -14,7 +14,7 @@ value = rays traced by the whole job (primary + shadow, counted by the instrumen
 
 Pipelining policy.  N = 1: `value` is one launch in flight, one frame per launch, frames back to back on one stream (the
 roofline block needs the kernel's own launch duration over the timed region); the throughput policy (4 launches in flight
-on alternating streams) is timed right after and reported as the labelled extra "pipelined" (5 % faster).  N > 1: `value`
+on alternating streams) is timed right after and reported as the labelled extra "pipelined".  N > 1: `value`
 is the throughput policy -- 4 launches in flight, from 8 ranks up 4 frames per launch -- because a rank's share of a
 1080p frame is tens of microseconds of work behind a tail of one grazing packet and a frame-end exchange, which only
 other frames' work can hide (one-GPU emulation, tools/dist_overhead.py: 8 ranks 121 us per frame with one launch in
