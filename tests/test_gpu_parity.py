@@ -551,6 +551,10 @@ def test_path_tracing_cornell_all_material_types(pkg, oracle, scenes, renderer):
         _compare_path(pkg, oracle, renderer, sc, 200, 120, 3, 5, 42, miss=(0.2, 0.3, 0.4))
         _compare_path(pkg, oracle, renderer, sc, 70, 50, 37, 2, 99)
         _compare_path(pkg, oracle, renderer, sc, 64, 64, 1, 0, 7)
+        # nothing to trace at all, and a scene whose every queue is shorter than one wavefront
+        nothing = {"meshes": [], "lights": [], "materials": [], "camera": {"position": np.float32([0, 0, 0]), "matrix": scenes.IDENTITY}}
+        _compare_path(pkg, oracle, renderer, nothing, 64, 48, 2, 2, 5, miss=(0.1, 0.2, 0.3))
+        _compare_path(pkg, oracle, renderer, scenes.single_triangle(), 33, 17, 3, 2, 11)
     finally:
         renderer.set_option("path_pass_paths", 1 << 24)
         renderer.set_option("path_pipeline", 0)
@@ -1220,6 +1224,7 @@ def test_random_scenes_property(pkg, oracle, scenes, renderer):
             if mode == pkg.MODE_PATH:
                 renderer.set_path_params(2, 2, seed)
                 oracle.set_path_params(2, 2, seed)
+                renderer.set_option("path_pipeline", seed & 1)  # persistent kernel / stage launches over global queues, alternating
             for counting in (False, True):
                 renderer.set_counting(counting)
                 got = renderer.render_frame(w, h)
@@ -1235,6 +1240,7 @@ def test_random_scenes_property(pkg, oracle, scenes, renderer):
         run()
     finally:
         renderer.set_counting(False)
+        renderer.set_option("path_pipeline", 0)
         renderer.set_path_params(4, 3, 1234)
         oracle.set_path_params(4, 3, 1234)
 
