@@ -205,6 +205,14 @@ def roofline_block(key, kernel, launch_ms, kernel_ms_median, cnt, alg_bytes):
     return out
 
 
+def default_policy(world, multi, path, inflight=0, batch=0):
+    """(launches in flight, frames per launch) of the timed region: see the module docstring.  0 = default."""
+    n_fly = inflight if inflight > 0 else (4 if multi else 1)
+    if not multi:
+        return n_fly, 1
+    return n_fly, (max(1, min(4, batch)) if batch > 0 else (4 if (world >= 8 and not path) else 1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -428,8 +436,7 @@ def main():
             elapsed = float(tmax.item())
         return elapsed, stream_ms, warmup + extra
 
-    n_fly = args.inflight if args.inflight > 0 else (4 if multi else 1)
-    batch = (max(1, min(4, args.batch)) if args.batch > 0 else (4 if (world >= 8 and not path) else 1)) if multi else 1
+    n_fly, batch = default_policy(world, multi, path, args.inflight, args.batch)
     step, state, streams = policy(n_fly, batch)
     if n_fly == 1 and not path:
         # scene setup, like the BVH build: the launch order of an unchanged view settles after each of the library's 4 scratch

@@ -62,3 +62,19 @@ def test_bench_starts_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo"],
                          capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(env, OMP_NUM_THREADS="2"))
     assert bad.returncode != 0  # (no GPU here: "bench.py needs an MI355X")
+
+
+def test_bench_pipelining_policy_defaults():
+    """bench.py: one launch in flight on one GPU (the roofline block times the kernel itself); four in flight on N > 1 ranks, four
+    frames per launch from 8 ranks up (not for path tracing, whose share of a frame is milliseconds); flags override."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.default_policy(1, False, False) == (1, 1)
+    assert b.default_policy(1, True, False) == (4, 1)       # --force-dist with the one rank a box has
+    assert b.default_policy(2, True, False) == (4, 1) and b.default_policy(4, True, False) == (4, 1)
+    assert b.default_policy(8, True, False) == (4, 4) and b.default_policy(8, True, True) == (4, 1)
+    assert b.default_policy(8, True, False, inflight=1, batch=1) == (1, 1)
+    assert b.default_policy(8, True, False, batch=9) == (4, 4) and b.default_policy(1, False, False, inflight=4, batch=3) == (4, 1)
