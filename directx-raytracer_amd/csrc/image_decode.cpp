@@ -544,10 +544,11 @@ DecodedImage decodeImage(const std::vector<unsigned char>& f, const std::string&
 {
     static const unsigned char pngMagic[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
     if (f.size() >= 8 && std::memcmp(f.data(), pngMagic, 8) == 0) return decodePng(f, what);
+    if (f.size() >= 3 && f[0] == 0xFF && f[1] == 0xD8 && f[2] == 0xFF) return decodeJpeg(f, what);
     if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') return decodeBmp(f, what);
     if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) return decodePnm(f, what);
     if (endsWith(what, ".tga")) return decodeTga(f, what); // TGA has no magic number: by its name
-    bad(what, "not a PNG, BMP, TGA or binary PPM / PGM file (JPEG, GIF, PSD, HDR and PIC, which the reference's stb_image also reads, are not supported)");
+    bad(what, "not a PNG, JPEG, BMP, TGA or binary PPM / PGM file (GIF, PSD, HDR and PIC, which the reference's stb_image also reads, are not supported)");
 }
 
 } // namespace crt

@@ -1,7 +1,8 @@
 // Bitmap texture files.  The reference loads whatever its vendored stb_image decodes (R/CRTTextureBitmap.cpp:10,
 // stbi_load(path, &w, &h, &channels, 0)); stb_image is third party and is not used here.  This decoder covers the formats a
-// .crtscene realistically names -- PNG (all colour types and bit depths, Adam7 interlace, tRNS), BMP (8-bit palette, 24 and 32
-// bit, uncompressed), TGA (true colour and grey, raw and run-length coded), binary PPM / PGM -- and yields what stbi_load yields
+// .crtscene realistically names -- PNG (all colour types and bit depths, Adam7 interlace, tRNS), JPEG (baseline and progressive,
+// jpeg_decode.cpp), BMP (8-bit palette, 24 and 32 bit, uncompressed), TGA (true colour and grey, raw and run-length coded), binary
+// PPM / PGM -- and yields what stbi_load yields
 // for them: rows top to bottom, `channels` bytes per texel in the file's own channel count (1 grey, 2 grey + alpha, 3 RGB,
 // 4 RGBA; 16-bit samples reduced to their high byte).  Known answers: tests/golden/texture_known_answers.json, produced by the
 // reference's own CRTTextureBitmap over the same files (oracle/make_golden.py).
@@ -20,6 +21,9 @@ struct DecodedImage {
 // `what` names the file in error messages.  Throws std::runtime_error on anything that is not a well-formed file of a supported
 // kind (never reads outside `file`, never allocates more than the header's width x height x 4 after checking it against 2^28 texels).
 DecodedImage decodeImage(const std::vector<unsigned char>& file, const std::string& what);
+
+// jpeg_decode.cpp: baseline / progressive Huffman JPEG with the reference decoder's numerical conventions (see the file's header)
+DecodedImage decodeJpeg(const std::vector<unsigned char>& file, const std::string& what);
 
 // RFC 1950 / 1951 (zlib stream around deflate), exposed for tests; throws std::runtime_error
 std::vector<unsigned char> zlibInflate(const unsigned char* data, size_t size, size_t expectedSize, const std::string& what);

@@ -69,7 +69,8 @@ def main():
         json.dump(json.load(open(ttmp)), f, separators=(",", ":"))
     # 4) bitmap textures in the other formats the reference's stb_image reads and this repo decodes itself (csrc/image_decode.cpp):
     #    seeded images written here (PNG: every colour type, 1 / 4 / 8 / 16 bits, all five filters, stored / fixed / dynamic deflate
-    #    blocks, Adam7; BMP: 24 / 32 bit, palette, top-down; TGA: raw / run-length, colour / grey), answers by CRTTextureBitmap
+    #    blocks, Adam7; BMP: 24 / 32 bit, palette, top-down; TGA: raw / run-length, colour / grey; JPEG: baseline / progressive,
+    #    4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey, CMYK, restart intervals, one-texel edges), answers by CRTTextureBitmap
     answers = {}
     for name, data in bitmap_fixtures().items():
         path = os.path.join(gold, name)
@@ -167,7 +168,8 @@ def _png(w, h, depth, color, rows, level=9, strategy=None, interlace=False, pale
     return out + chunk(b"IEND", b"")
 
 
-ONE_CHANNEL = {"tex_grey8_stored.png": (9, 6), "tex_grey1.png": (13, 6), "tex_grey8.tga": (9, 6)}  # name -> (width, height)
+ONE_CHANNEL = {"tex_grey8_stored.png": (9, 6), "tex_grey1.png": (13, 6), "tex_grey8.tga": (9, 6), "tex_grey.jpg": (21, 19),
+               "tex_proggrey.jpg": (20, 21)}  # name -> (width, height)
 
 
 def bitmap_fixtures():
@@ -251,6 +253,36 @@ def bitmap_fixtures():
     flat[2:4, 1:7] = flat[2, 1]   # runs for the run-length coder
     fx["tex_32_rle_topleft.tga"] = tga(w, h, 32, [flat[y][:, [2, 1, 0, 3]].tobytes() for y in range(h)], 2, top_left=True, rle=True)
     fx["tex_grey8.tga"] = tga(w, h, 8, [grey[y].tobytes() for y in range(h)], 3)
+
+    # JPEG: written by Pillow's libjpeg (any encoder would do: the known answers come from the reference's decoder).  Smooth
+    # content + noise so that every frequency band carries something; 21 x 19 texels are covered completely by the 21 x 21 grid
+    # of sample points, two MCUs across and down at every subsampling.
+    import io
+    from PIL import Image
+
+    def jpeg(name, size, mode, **kw):
+        wj, hj = size
+        yy, xx = np.mgrid[0:hj, 0:wj]
+        ch = {"RGB": 3, "L": 1, "CMYK": 4}[mode]
+        a = np.stack([(xx * 7 + yy * 3 + 40 * np.sin(xx / 3.0 + k)) % 256 for k in range(ch)], -1) + rng.integers(-20, 20, (hj, wj, ch))
+        a = np.clip(a, 0, 255).astype(np.uint8)
+        buf = io.BytesIO()
+        Image.fromarray(a[:, :, 0] if ch == 1 else a, mode=mode).save(buf, format="JPEG", **kw)
+        fx[name] = buf.getvalue()
+    jpeg("tex_444.jpg", (21, 19), "RGB", quality=90, subsampling=0)
+    jpeg("tex_422.jpg", (21, 19), "RGB", quality=85, subsampling=1)
+    jpeg("tex_420.jpg", (21, 19), "RGB", quality=75, subsampling=2)
+    jpeg("tex_411.jpg", (21, 19), "RGB", quality=80, subsampling="4:1:1")
+    jpeg("tex_grey.jpg", (21, 19), "L", quality=80)
+    jpeg("tex_prog420.jpg", (21, 19), "RGB", quality=70, subsampling=2, progressive=True)
+    jpeg("tex_prog444_opt.jpg", (21, 19), "RGB", quality=95, subsampling=0, progressive=True, optimize=True)
+    jpeg("tex_proggrey.jpg", (20, 21), "L", quality=50, progressive=True)
+    jpeg("tex_q10.jpg", (21, 19), "RGB", quality=10, subsampling=2)
+    jpeg("tex_rst.jpg", (64, 40), "RGB", quality=60, subsampling=2, restart_marker_blocks=3)
+    jpeg("tex_cmyk.jpg", (21, 19), "CMYK", quality=90)
+    jpeg("tex_1x1.jpg", (1, 1), "RGB", quality=90, subsampling=2)
+    jpeg("tex_2x1.jpg", (2, 1), "RGB", quality=90, subsampling=2)
+    jpeg("tex_1x9.jpg", (1, 9), "RGB", quality=90, subsampling=1)
     return fx
 
 

@@ -957,38 +957,38 @@ def test_textured_scene(pkg, oracle, scenes, renderer):
 
 
 def test_scene_file_with_png_and_tga_textures_on_the_device(pkg, oracle, scenes, renderer, tmp_path, golden_dir):
-    """A .crtscene whose bitmap textures are a PNG (RGBA, fixed-Huffman deflate) and a run-length coded TGA -- files the
-    reference's stbi_load accepts (R/CRTTextureBitmap.cpp:10) and this repo decodes itself -- through crt_scene_load ->
-    crt_upload_scene_from -> the kernels: the frame equals the oracle's, whose bitmap is rebuilt texel by texel from the host
-    class that tests/golden/bitmap_known_answers.json pins to the reference."""
+    """A .crtscene whose bitmap textures are a PNG (RGBA, fixed-Huffman deflate), a run-length coded TGA and a progressive 4:2:0
+    JPEG -- files the reference's stbi_load accepts (R/CRTTextureBitmap.cpp:10) and this repo decodes itself -- through
+    crt_scene_load -> crt_upload_scene_from -> the kernels: the frame equals the oracle's, whose bitmap is rebuilt texel by texel
+    from the host class that tests/golden/bitmap_known_answers.json pins to the reference."""
     import json
     quad = lambda x0, x1, z: [[x0, -1, z], [x1, -1, z], [x1, 1, z], [x0, 1, z]]
     objs = []
-    for i, (x0, x1) in enumerate(((-2.2, -0.1), (0.1, 2.2))):
+    for i, (x0, x1) in enumerate(((-3.3, -1.2), (-1.05, 1.05), (1.2, 3.3))):
         objs.append({"material_index": i, "vertices": [c for v in quad(x0, x1, -3.0) for c in v], "triangles": [0, 1, 2, 0, 2, 3],
                      "uvs": [0, 0, 0, 1, 0, 0, 1, 1, 0, 0, 1, 0]})
+    files = (("png", "tex_rgba8_fixed.png", 9, 6), ("tga", "tex_32_rle_topleft.tga", 9, 6), ("jpg", "tex_prog420.jpg", 21, 19))
     scene = {"settings": {"background_color": [0, 0, 0], "image_settings": {"width": 320, "height": 200}},
              "camera": {"matrix": [1, 0, 0, 0, 1, 0, 0, 0, 1], "position": [0, 0, 0]},
              "lights": [{"intensity": 400, "position": [0, 1, 2]}],
-             "textures": [{"name": "png", "type": "bitmap", "file_path": os.path.join(golden_dir, "tex_rgba8_fixed.png")},
-                          {"name": "tga", "type": "bitmap", "file_path": os.path.join(golden_dir, "tex_32_rle_topleft.tga")}],
-             "materials": [{"type": "diffuse", "albedo": "png", "smooth_shading": False}, {"type": "diffuse", "albedo": "tga", "smooth_shading": False}],
+             "textures": [{"name": n, "type": "bitmap", "file_path": os.path.join(golden_dir, f)} for n, f, _, _ in files],
+             "materials": [{"type": "diffuse", "albedo": n, "smooth_shading": False} for n, _, _, _ in files],
              "objects": objs}
     path = tmp_path / "textured.crtscene"
     path.write_text(json.dumps(scene))
     s = pkg.Scene(str(path))
-    assert s.texture_count == 2 and [m["texture"] for m in s.materials()] == [0, 1]
+    assert s.texture_count == 3 and [m["texture"] for m in s.materials()] == [0, 1, 2]
     renderer.upload_scene(s)
     renderer.set_camera_from(s)
     pos, rot = s.camera()
-    # the oracle's copy of the two bitmaps: every texel through the host class (9 x 6 texels each, v flipped)
+    # the oracle's copy of the bitmaps: every texel through the host class (v flipped)
     tex = []
-    for i in range(2):
-        px = np.zeros((6, 9, 3), np.uint8)
-        for row in range(6):
-            for col in range(9):
+    for i, (_, _, tw, th) in enumerate(files):
+        px = np.zeros((th, tw, 3), np.uint8)
+        for row in range(th):
+            for col in range(tw):
                 # (aimed a quarter texel inside: the class truncates u * (w - 1) and (1 - v) * (h - 1), and clamps u, v to [0, 1])
-                c = s.texture_color(i, (np.float32(col) + np.float32(0.25)) / np.float32(8), np.float32(1) - (np.float32(row) + np.float32(0.25)) / np.float32(5))
+                c = s.texture_color(i, (np.float32(col) + np.float32(0.25)) / np.float32(tw - 1), np.float32(1) - (np.float32(row) + np.float32(0.25)) / np.float32(th - 1))
                 px[row, col] = np.round(c * 255.0).astype(np.uint8)
         tex.append({"type": "bitmap", "pixels": px})
     meshes = [dict(vertices=m["vertices"], triangles=m["triangles"], normals=m["normals"], uvs=m["uvs"], material_index=m["material_index"]) for m in s.meshes()]
@@ -999,7 +999,7 @@ def test_scene_file_with_png_and_tga_textures_on_the_device(pkg, oracle, scenes,
     np.testing.assert_array_equal(got["hit_prim"], ref["hit_prim"])
     np.testing.assert_array_equal(got["rgba8"], ref["rgba8"])
     assert np.array_equal(got["rgb"], ref["rgb"], equal_nan=True)
-    assert len(np.unique(got["rgba8"].reshape(-1, 4), axis=0)) > 60  # both bitmaps are in the picture
+    assert len(np.unique(got["rgba8"].reshape(-1, 4), axis=0)) > 120  # all three bitmaps are in the picture
 
 
 def test_frames_in_flight_and_launch_order_feedback(pkg, oracle, scenes, dragon, renderer):

@@ -237,13 +237,16 @@ def test_texture_classes_match_the_reference(pkg, oracle, golden_dir):
 
 def test_bitmap_formats_match_the_reference(pkg, golden_dir):
     """Bitmap textures in the formats a .crtscene realistically names.  The reference decodes them with its vendored stb_image
-    (R/CRTTextureBitmap.cpp:10); this repo with its own decoder (csrc/image_decode.cpp: PNG with its own inflate, BMP, TGA).
-    Known answers: the reference's CRTTextureBitmap::getColor over the same seeded files (oracle/make_golden.py), bit for bit --
-    PNG in every colour type (grey, grey + alpha, RGB, RGBA, palette with and without tRNS), 1 / 4 / 8 / 16 bits, all five
-    scanline filters, stored / fixed / dynamic deflate blocks, several IDAT chunks, Adam7; BMP 24 / 32 bit / palette / top-down;
-    TGA raw and run-length coded, colour and grey."""
+    (R/CRTTextureBitmap.cpp:10); this repo with its own decoders (csrc/image_decode.cpp: PNG with its own inflate, BMP, TGA;
+    csrc/jpeg_decode.cpp).  Known answers: the reference's CRTTextureBitmap::getColor over the same seeded files
+    (oracle/make_golden.py), bit for bit -- PNG in every colour type (grey, grey + alpha, RGB, RGBA, palette with and without
+    tRNS), 1 / 4 / 8 / 16 bits, all five scanline filters, stored / fixed / dynamic deflate blocks, several IDAT chunks, Adam7;
+    BMP 24 / 32 bit / palette / top-down; TGA raw and run-length coded, colour and grey; JPEG baseline and progressive (also
+    with optimised Huffman tables), 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey, Adobe CMYK, restart intervals, quality 10, and images one
+    or two texels wide -- a JPEG's texels depend on the decoder's inverse DCT, chroma filter and colour matrix, so these pin the
+    arithmetic, not only the parsing."""
     answers = json.load(open(os.path.join(golden_dir, "bitmap_known_answers.json")))
-    assert len(answers) >= 17
+    assert len(answers) >= 31 and sum(n.endswith(".jpg") for n in answers) >= 14
     f32 = np.float32
     for name, rows in sorted(answers.items()):
         s = pkg.Scene()
@@ -280,17 +283,22 @@ def test_damaged_bitmap_files_are_errors_not_crashes(pkg, golden_dir, tmp_path):
                 failed += 1
             path.unlink()
     assert tried > 1000 and failed > tried // 4
-    # formats the reference's stb_image reads and this decoder does not: a clear error naming them
-    jpg = tmp_path / "x.jpg"
-    jpg.write_bytes(b"\xff\xd8\xff\xe0" + b"\0" * 64)
+    # formats the reference's stb_image reads and this decoder does not (GIF, PSD, HDR, PIC): a clear error naming them
+    gif = tmp_path / "x.gif"
+    gif.write_bytes(b"GIF89a" + b"\0" * 64)
     with pytest.raises(pkg.CrtError):
-        pkg.Scene().add_texture("b", "bitmap", file_path=str(jpg))
-    scene = tmp_path / "jpg.crtscene"
+        pkg.Scene().add_texture("b", "bitmap", file_path=str(gif))
+    scene = tmp_path / "gif.crtscene"
     scene.write_text('{"settings":{"background_color":[0,0,0],"image_settings":{"width":4,"height":4}},'
                      '"camera":{"matrix":[1,0,0,0,1,0,0,0,1],"position":[0,0,0]},"lights":[],"materials":[],'
-                     '"textures":[{"name":"t","type":"bitmap","file_path":"x.jpg"}],"objects":[]}')
-    with pytest.raises(pkg.CrtError, match="JPEG"):
+                     '"textures":[{"name":"t","type":"bitmap","file_path":"x.gif"}],"objects":[]}')
+    with pytest.raises(pkg.CrtError, match="GIF"):
         pkg.Scene(str(scene))
+    # a JPEG kind this decoder does not read (arithmetic coding) says so
+    arith = tmp_path / "arith.jpg"
+    arith.write_bytes(b"\xff\xd8\xff\xc9\x00\x0b\x08\x00\x04\x00\x04\x01\x01\x11\x00\xff\xd9")
+    with pytest.raises(pkg.CrtError):
+        pkg.Scene().add_texture("b", "bitmap", file_path=str(arith))
 
 
 def test_textured_scene_file(pkg, tmp_path, golden_dir):

@@ -7,11 +7,11 @@ ROOT="$(cd "$(dirname "$0")/.." && pwd)"
 cd "$ROOT/directx-raytracer_amd/csrc"
 make -j8 > /dev/null
 mkdir -p build/asan
-for f in scene image_decode scene_parser bvh_build crt_api renderer; do
+for f in scene image_decode jpeg_decode scene_parser bvh_build crt_api renderer; do
   g++ -std=c++17 -O1 -g -fPIC -ffp-contract=off -fno-fast-math -fopenmp -fsanitize=address,undefined -fno-omit-frame-pointer \
       -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -c $f.cpp -o build/asan/$f.o
 done
-g++ -shared -o ../libcrt_hip_asan.so build/asan/{scene,image_decode,scene_parser,bvh_build,crt_api,renderer}.o build/render_kernels.o build/path_kernels.o build/bvh_gpu.o \
+g++ -shared -o ../libcrt_hip_asan.so build/asan/{scene,image_decode,jpeg_decode,scene_parser,bvh_build,crt_api,renderer}.o build/render_kernels.o build/path_kernels.o build/bvh_gpu.o \
     -L/opt/rocm/lib -lamdhip64 -ldl -fopenmp -fsanitize=address,undefined -Wl,-rpath,/opt/rocm/lib
 cd "$ROOT"
 # libstdc++ is preloaded beside libasan so that the __cxa_throw interceptor resolves inside the python process
