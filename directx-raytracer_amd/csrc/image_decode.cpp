@@ -527,6 +527,173 @@ DecodedImage decodePnm(const std::vector<unsigned char>& f, const std::string& w
     return img;
 }
 
+// GIF 87a / 89a: the FIRST image of the file on a transparent-black canvas, four bytes per texel (what the reference's stb_image
+// hands to R/CRTTextureBitmap.cpp:10 for a GIF; conventions studied in R/stb_image/stb_image.h:6702-7060).  Indices whose palette
+// entry is the graphic-control extension's transparent colour leave the canvas untouched; where the first image does not cover
+// the canvas and the header names a background index above 0, the uncovered texels take that palette entry -- with red and blue
+// exchanged, as that decoder stores it (it copies its B, G, R, A palette entry without the swap it applies to drawn texels).
+// A file that ends inside the image data yields the rows decoded so far (its reader returns zeros past the end, and a zero is
+// the data's own terminator); a damaged code stream is an error.
+DecodedImage decodeGif(const std::vector<unsigned char>& f, const std::string& what)
+{
+    size_t at = 6;
+    auto u8 = [&]() -> unsigned { return at < f.size() ? f[at++] : (at++, 0u); };
+    auto u16 = [&]() -> unsigned { const unsigned lo = u8(); return lo | (u8() << 8); };
+    if (f.size() < 13 || (f[4] != '7' && f[4] != '9') || f[5] != 'a') bad(what, "not a GIF 87a / 89a file");
+    DecodedImage img;
+    img.width = static_cast<int>(u16());
+    img.height = static_cast<int>(u16());
+    const unsigned flags = u8(), background = u8();
+    u8(); // aspect ratio
+    if (img.width == 0 || img.height == 0) bad(what, "GIF canvas without an extent");
+    if (static_cast<uint64_t>(img.width) * static_cast<uint64_t>(img.height) > (1ull << 28)) bad(what, "more than 2^28 texels");
+    struct Entry { unsigned char r, g, b, a; };
+    Entry global[256] = {}, local[256] = {};
+    auto readTable = [&](Entry* t, unsigned n, int transparent) {
+        for (unsigned i = 0; i < n; i++) {
+            t[i].r = static_cast<unsigned char>(u8());
+            t[i].g = static_cast<unsigned char>(u8());
+            t[i].b = static_cast<unsigned char>(u8());
+            t[i].a = static_cast<int>(i) == transparent ? 0 : 255;
+        }
+    };
+    if (flags & 0x80) readTable(global, 2u << (flags & 7), -1);
+    img.channels = 4;
+    const size_t texels = static_cast<size_t>(img.width) * img.height;
+    img.pixels.assign(texels * 4, 0);
+    std::vector<unsigned char> drawn(texels, 0);
+    unsigned control = 0;
+    int transparent = -1;
+    for (;;) {
+        const unsigned tag = u8();
+        if (tag == 0x21) { // extension: only the graphic control block matters (transparent colour)
+            const unsigned label = u8();
+            unsigned len;
+            if (label == 0xF9) {
+                len = u8();
+                if (len == 4) {
+                    control = u8();
+                    u16(); // delay
+                    if (transparent >= 0) global[transparent].a = 255;
+                    if (control & 1) {
+                        transparent = static_cast<int>(u8());
+                        global[transparent].a = 0;
+                    } else {
+                        u8();
+                        transparent = -1;
+                    }
+                } else {
+                    at += len;
+                    continue;
+                }
+            }
+            while ((len = u8()) != 0) at += len;
+            if (at > f.size() + 4096) bad(what, "GIF extension runs past the end of the file");
+            continue;
+        }
+        if (tag != 0x2C) bad(what, tag == 0x3B ? "GIF without an image" : "unknown block in a GIF");
+        const unsigned x0 = u16(), y0 = u16(), w = u16(), h = u16();
+        if (x0 + w > static_cast<unsigned>(img.width) || y0 + h > static_cast<unsigned>(img.height)) bad(what, "GIF image outside its canvas");
+        const unsigned lflags = u8();
+        const Entry* table = global;
+        if (lflags & 0x80) {
+            readTable(local, 2u << (lflags & 7), (control & 1) ? transparent : -1);
+            table = local;
+        } else if (!(flags & 0x80)) {
+            bad(what, "GIF image without a colour table");
+        }
+        // rows in the order they are stored: every row once, or four interlace passes (every 8th from 0, every 8th from 4, every
+        // 4th from 2, every 2nd from 1)
+        unsigned row = 0, step = (lflags & 0x40) ? 8u : 1u, pass = (lflags & 0x40) ? 3u : 0u, col = 0;
+        bool rowsLeft = w != 0 && h != 0;
+        auto put = [&](unsigned index) {
+            if (!rowsLeft) return;
+            const size_t t = static_cast<size_t>(y0 + row) * img.width + x0 + col;
+            drawn[t] = 1;
+            const Entry& e = table[index];
+            if (e.a > 128) {
+                unsigned char* p = img.pixels.data() + 4 * t;
+                p[0] = e.r; p[1] = e.g; p[2] = e.b; p[3] = e.a;
+            }
+            if (++col >= w) {
+                col = 0;
+                row += step;
+                while (row >= h && pass > 0) {
+                    step = 1u << pass;
+                    row = step >> 1;
+                    pass--;
+                }
+                if (row >= h) rowsLeft = false;
+            }
+        };
+        // LZW, variable code size, least significant bit first, data in sub-blocks of up to 255 bytes
+        const unsigned minSize = u8();
+        if (minSize > 12) bad(what, "GIF code size above 12");
+        const int clear = 1 << minSize;
+        struct Code { int16_t prefix; unsigned char first, suffix; };
+        std::vector<Code> codes(8192);
+        for (int i = 0; i < clear; i++) codes[static_cast<size_t>(i)] = { -1, static_cast<unsigned char>(i), static_cast<unsigned char>(i) };
+        int size = static_cast<int>(minSize) + 1, mask = (1 << size) - 1, avail = clear + 2, old = -1;
+        bool sawClear = false;
+        uint32_t bits = 0;
+        int have = 0;
+        unsigned left = 0;
+        std::vector<unsigned char> run(8192);
+        for (;;) {
+            if (have < size) {
+                if (left == 0) {
+                    left = u8();
+                    if (left == 0) break; // terminator (or the end of a truncated file)
+                }
+                left--;
+                bits |= static_cast<uint32_t>(u8()) << have;
+                have += 8;
+                continue;
+            }
+            const int code = static_cast<int>(bits & static_cast<uint32_t>(mask));
+            bits >>= size;
+            have -= size;
+            if (code == clear) {
+                size = static_cast<int>(minSize) + 1;
+                mask = (1 << size) - 1;
+                avail = clear + 2;
+                old = -1;
+                sawClear = true;
+            } else if (code == clear + 1) {
+                break; // end of information: whatever follows in the file is not needed for the first image
+            } else if (code <= avail) {
+                if (!sawClear) bad(what, "GIF image data does not start with a clear code");
+                if (old >= 0) {
+                    if (avail >= 8192) bad(what, "GIF image data defines more than 8192 codes");
+                    Code& c = codes[static_cast<size_t>(avail++)];
+                    c.prefix = static_cast<int16_t>(old);
+                    c.first = codes[static_cast<size_t>(old)].first;
+                    c.suffix = codes[static_cast<size_t>(code)].first; // (for the code being defined right now that is c.first itself)
+                } else if (code == avail) {
+                    bad(what, "GIF image data uses a code before defining it");
+                }
+                size_t n = 0;
+                for (int k = code; k >= 0; k = codes[static_cast<size_t>(k)].prefix) run[n++] = codes[static_cast<size_t>(k)].suffix;
+                while (n) put(run[--n]);
+                if ((avail & mask) == 0 && avail <= 0x0FFF) {
+                    size++;
+                    mask = (1 << size) - 1;
+                }
+                old = code;
+            } else {
+                bad(what, "GIF image data uses a code before defining it");
+            }
+        }
+        if (background > 0)
+            for (size_t t = 0; t < texels; t++)
+                if (!drawn[t]) {
+                    unsigned char* p = img.pixels.data() + 4 * t;
+                    p[0] = global[background].b; p[1] = global[background].g; p[2] = global[background].r; p[3] = 255;
+                }
+        return img;
+    }
+}
+
 bool endsWith(const std::string& s, const char* suffix)
 {
     const size_t n = std::strlen(suffix);
@@ -545,10 +712,11 @@ DecodedImage decodeImage(const std::vector<unsigned char>& f, const std::string&
     static const unsigned char pngMagic[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
     if (f.size() >= 8 && std::memcmp(f.data(), pngMagic, 8) == 0) return decodePng(f, what);
     if (f.size() >= 3 && f[0] == 0xFF && f[1] == 0xD8 && f[2] == 0xFF) return decodeJpeg(f, what);
+    if (f.size() >= 6 && std::memcmp(f.data(), "GIF8", 4) == 0) return decodeGif(f, what);
     if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') return decodeBmp(f, what);
     if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) return decodePnm(f, what);
     if (endsWith(what, ".tga")) return decodeTga(f, what); // TGA has no magic number: by its name
-    bad(what, "not a PNG, JPEG, BMP, TGA or binary PPM / PGM file (GIF, PSD, HDR and PIC, which the reference's stb_image also reads, are not supported)");
+    bad(what, "not a PNG, JPEG, GIF, BMP, TGA or binary PPM / PGM file (PSD, HDR and PIC, which the reference's stb_image also reads, are not supported)");
 }
 
 } // namespace crt

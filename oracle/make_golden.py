@@ -283,6 +283,63 @@ def bitmap_fixtures():
     jpeg("tex_1x1.jpg", (1, 1), "RGB", quality=90, subsampling=2)
     jpeg("tex_2x1.jpg", (2, 1), "RGB", quality=90, subsampling=2)
     jpeg("tex_1x9.jpg", (1, 9), "RGB", quality=90, subsampling=1)
+
+    # GIF: Pillow's encoder for whole-canvas images (palette, interlaced, transparent index), and a hand-assembled file whose first
+    # image covers only part of the canvas (background index, local colour table, graphic control extension)
+    def pil_gif(name, size, **kw):
+        wg, hg = size
+        im = Image.fromarray(rng.integers(0, 64, (hg, wg), dtype=np.uint8), mode="P")
+        im.putpalette(rng.integers(0, 256, 64 * 3, dtype=np.uint8).tolist())
+        buf = io.BytesIO()
+        im.save(buf, format="GIF", **kw)
+        fx[name] = buf.getvalue()
+    pil_gif("tex_pal.gif", (9, 6))
+    pil_gif("tex_interlaced.gif", (21, 19), interlace=True)
+    pil_gif("tex_transparent.gif", (9, 6), transparency=5)
+
+    def raw_gif(wc, hc, bg, table, x0, y0, wi, hi, indices, local=None, transparent=None, interlace=False):
+        bits = max(2, (len(local or table) - 1).bit_length())
+        out = bytearray(b"GIF89a" + struct.pack("<HHBBB", wc, hc, 0x80 | ((len(table).bit_length() - 2) & 7), bg, 0))
+        out += bytes(c for e in table for c in e)
+        if transparent is not None:
+            out += bytes([0x21, 0xF9, 4, 1, 0, 0, transparent, 0])
+        out += b"\x21\xFE\x06seeded\x00"  # a comment extension to skip
+        out += b"\x2C" + struct.pack("<HHHHB", x0, y0, wi, hi, (0x40 if interlace else 0) | ((0x80 | ((len(local).bit_length() - 2) & 7)) if local else 0))
+        if local:
+            out += bytes(c for e in local for c in e)
+        clear, codes, size = 1 << bits, [], bits + 1
+        rows = list(range(hi))
+        if interlace:
+            rows = list(range(0, hi, 8)) + list(range(4, hi, 8)) + list(range(2, hi, 4)) + list(range(1, hi, 2))
+        stream = [indices[r][c] for r in rows for c in range(wi)]
+        # literal codes only, a clear code often enough that the code size never grows (valid LZW, no compression)
+        per = (1 << size) - clear - 3
+        for i, v in enumerate(stream):
+            if i % per == 0:
+                codes.append(clear)
+            codes.append(int(v))
+        codes.append(clear + 1)
+        acc = n = 0
+        data = bytearray()
+        for c in codes:
+            acc |= c << n
+            n += size
+            while n >= 8:
+                data.append(acc & 255)
+                acc >>= 8
+                n -= 8
+        if n:
+            data.append(acc & 255)
+        out.append(bits)
+        for i in range(0, len(data), 200):
+            out.append(len(data[i:i + 200]))
+            out += data[i:i + 200]
+        return bytes(out + b"\x00\x3B")
+    tab8 = [tuple(int(x) for x in rng.integers(0, 256, 3)) for _ in range(8)]
+    loc16 = [tuple(int(x) for x in rng.integers(0, 256, 3)) for _ in range(16)]
+    fx["tex_partial_bg.gif"] = raw_gif(9, 6, 3, tab8, 2, 1, 5, 3, rng.integers(0, 8, (3, 5)))
+    fx["tex_partial_local_transparent.gif"] = raw_gif(9, 6, 2, tab8, 1, 1, 7, 4, rng.integers(0, 16, (4, 7)), local=loc16, transparent=6)
+    fx["tex_partial_interlaced.gif"] = raw_gif(21, 19, 0, tab8, 3, 2, 15, 13, rng.integers(0, 8, (13, 15)), interlace=True)
     return fx
 
 

@@ -244,9 +244,11 @@ def test_bitmap_formats_match_the_reference(pkg, golden_dir):
     BMP 24 / 32 bit / palette / top-down; TGA raw and run-length coded, colour and grey; JPEG baseline and progressive (also
     with optimised Huffman tables), 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey, Adobe CMYK, restart intervals, quality 10, and images one
     or two texels wide -- a JPEG's texels depend on the decoder's inverse DCT, chroma filter and colour matrix, so these pin the
-    arithmetic, not only the parsing."""
+    arithmetic, not only the parsing; GIF (first image, four channels): global and local colour tables, interlaced, transparent
+    index, an image smaller than its canvas with a background index (red and blue exchanged there, as the reference's decoder
+    leaves them)."""
     answers = json.load(open(os.path.join(golden_dir, "bitmap_known_answers.json")))
-    assert len(answers) >= 31 and sum(n.endswith(".jpg") for n in answers) >= 14
+    assert len(answers) >= 37 and sum(n.endswith(".jpg") for n in answers) >= 14 and sum(n.endswith(".gif") for n in answers) >= 6
     f32 = np.float32
     for name, rows in sorted(answers.items()):
         s = pkg.Scene()
@@ -283,17 +285,23 @@ def test_damaged_bitmap_files_are_errors_not_crashes(pkg, golden_dir, tmp_path):
                 failed += 1
             path.unlink()
     assert tried > 1000 and failed > tried // 4
-    # formats the reference's stb_image reads and this decoder does not (GIF, PSD, HDR, PIC): a clear error naming them
-    gif = tmp_path / "x.gif"
-    gif.write_bytes(b"GIF89a" + b"\0" * 64)
+    # formats the reference's stb_image reads and this decoder does not (PSD, HDR, PIC): a clear error naming them
+    psd = tmp_path / "x.psd"
+    psd.write_bytes(b"8BPS\0\1" + b"\0" * 64)
     with pytest.raises(pkg.CrtError):
-        pkg.Scene().add_texture("b", "bitmap", file_path=str(gif))
-    scene = tmp_path / "gif.crtscene"
+        pkg.Scene().add_texture("b", "bitmap", file_path=str(psd))
+    scene = tmp_path / "psd.crtscene"
     scene.write_text('{"settings":{"background_color":[0,0,0],"image_settings":{"width":4,"height":4}},'
                      '"camera":{"matrix":[1,0,0,0,1,0,0,0,1],"position":[0,0,0]},"lights":[],"materials":[],'
-                     '"textures":[{"name":"t","type":"bitmap","file_path":"x.gif"}],"objects":[]}')
-    with pytest.raises(pkg.CrtError, match="GIF"):
+                     '"textures":[{"name":"t","type":"bitmap","file_path":"x.psd"}],"objects":[]}')
+    with pytest.raises(pkg.CrtError, match="PSD"):
         pkg.Scene(str(scene))
+    # a GIF whose canvas has no extent, and one without any image
+    for blob in (b"GIF89a" + b"\0" * 64, b"GIF89a\x02\x00\x02\x00\x00\x00\x00\x3B"):
+        gif = tmp_path / "x.gif"
+        gif.write_bytes(blob)
+        with pytest.raises(pkg.CrtError):
+            pkg.Scene().add_texture("b", "bitmap", file_path=str(gif))
     # a JPEG kind this decoder does not read (arithmetic coding) says so
     arith = tmp_path / "arith.jpg"
     arith.write_bytes(b"\xff\xd8\xff\xc9\x00\x0b\x08\x00\x04\x00\x04\x01\x01\x11\x00\xff\xd9")
