@@ -211,13 +211,14 @@ def test_c3_tiled_over_2_4_8_ranks_vs_oracle(pkg, oracle, scenes, renderer):
         np.testing.assert_array_equal(frame.cpu().numpy().view(np.uint32), ref, err_msg="n_ranks=%d" % n)
         # batched variant (several frames per launch, as bench.py does from 8 ranks up): same frames
         if n == 8:
-            g2 = torch.zeros(n * 2 * slots * 256, dtype=torch.int32, device="cuda")
+            nb = 4  # bench.py's frames per launch at 8 ranks
+            g2 = torch.zeros(n * nb * slots * 256, dtype=torch.int32, device="cuda")
             torch.cuda.synchronize()
             for rank in range(n):
-                base = g2.data_ptr() + rank * 2 * slots * 1024
-                renderer.render_tiles_batch_device(w, h, rank, n, [base, base + slots * 1024])
-            for f in range(2):
-                renderer.untile_batch_device(w, h, n, 2, f, g2.data_ptr(), frame.data_ptr())
+                base = g2.data_ptr() + rank * nb * slots * 1024
+                renderer.render_tiles_batch_device(w, h, rank, n, [base + f * slots * 1024 for f in range(nb)])
+            for f in range(nb):
+                renderer.untile_batch_device(w, h, n, nb, f, g2.data_ptr(), frame.data_ptr())
                 renderer.synchronize()
                 np.testing.assert_array_equal(frame.cpu().numpy().view(np.uint32), ref, err_msg="batched frame %d" % f)
 
