@@ -258,7 +258,10 @@ def bitmap_fixtures():
     # content + noise so that every frequency band carries something; 21 x 19 texels are covered completely by the 21 x 21 grid
     # of sample points, two MCUs across and down at every subsampling.
     import io
-    from PIL import Image
+    try:
+        from PIL import Image
+    except ImportError as e:  # only needed to REGENERATE: the committed fixtures and their known answers stay valid without it
+        raise SystemExit("oracle/make_golden.py: Pillow is needed to write the JPEG / GIF fixtures again (%s)" % e)
 
     def jpeg(name, size, mode, **kw):
         wj, hj = size
