@@ -3,7 +3,7 @@
 // camera path through the same Camera calls the reference's input handlers make -- W/S -> moveForward, A/D ->
 // moveRight (R/DXRTApp.cpp:91-107), mouse -> rotate (R/DXRTViewportWidget.cpp:50-72), wheel -> zoom (:74-78) -- and
 // the shading-mode switch of its combo box (R/DXRTMainWindow.cpp:114-121), renders N frames, prints ms/frame and
-// Mray/s (the reference shows an FPS label, R/DXRTApp.cpp:82-90) and optionally writes PPM images.
+// Mray/s (the reference shows an FPS label, R/DXRTApp.cpp:82-90) and optionally writes PPM or PNG images.
 //
 // --ranks N: one process per GPU, launched from here, no Python: the parent (which never touches the GPU) starts N
 // copies of itself with --rank r; rank r renders on device r, the frame is tile-partitioned and assembled with one
@@ -36,7 +36,7 @@ static void usage()
                  "   [--mode-at FRAME:MODE]...  switch the shading mode from that frame on\n"
                  "   [--spp N] [--bounces N] [--seed N]   mode 200 (path tracing)\n"
                  "   [--phong KS_PERMILLE:EXPONENT]       mode 100 specular term\n"
-                 "   [--out prefix] [--count]\n"
+                 "   [--out prefix] [--png] [--count]      frames as prefix_N.ppm, or prefix_N.png with --png\n"
                  "   [--ranks N [--device-base D] [--id-file PATH]]   N processes / GPUs, RCCL gather per frame\n");
 }
 
@@ -47,7 +47,7 @@ struct Args {
     int frames = 1, device = 0, deviceBase = 0, ranks = 0, rank = -1;
     int spp = -1, bounces = -1, seed = -1, phongKs = -1, phongExp = -1;
     float orbit = 0.f, pitch = 0.f, forward = 0.f, right = 0.f, zoom = 0.f;
-    bool count = false;
+    bool count = false, png = false;
     unsigned long long nonce = 0; // names the launch in the id file (set by the --ranks parent)
     std::map<int, uint32_t> modeAt;
 };
@@ -122,7 +122,10 @@ int runRank(const Args& a)
         if (a.count) std::printf(", nodes %llu, tris %llu, shadow rays %llu", (unsigned long long)st.nodes_visited,
                                  (unsigned long long)st.tris_tested, (unsigned long long)st.rays_shadow);
         std::printf("\n");
-        if (!a.out.empty()) renderer.writePPM(a.out + "_" + std::to_string(f) + ".ppm");
+        if (!a.out.empty()) {
+            if (a.png) renderer.writePNG(a.out + "_" + std::to_string(f) + ".png");
+            else renderer.writePPM(a.out + "_" + std::to_string(f) + ".ppm");
+        }
     }
     if (talk) std::printf("average kernel %.3f ms/frame over %d frames (%ux%u, mode %u)\n", sumMs / a.frames, a.frames, a.w, a.h, a.mode);
     renderer.stopRendering();
@@ -237,6 +240,7 @@ int main(int argc, char** argv)
         else if (s == "--phong") { if (std::sscanf(next("--phong"), "%d:%d", &a.phongKs, &a.phongExp) != 2) { usage(); return 2; } }
         else if (s == "--out") a.out = next("--out");
         else if (s == "--count") a.count = true;
+        else if (s == "--png") a.png = true;
         else if (s == "--ranks") a.ranks = std::atoi(next("--ranks"));
         else if (s == "--rank") a.rank = std::atoi(next("--rank"));
         else if (s == "--device-base") a.deviceBase = std::atoi(next("--device-base"));

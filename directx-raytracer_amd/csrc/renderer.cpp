@@ -1,7 +1,9 @@
 #include "renderer.h"
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
+#include <cstring>
 #include <stdexcept>
 #include <thread>
 
@@ -177,6 +179,74 @@ void Renderer::writePPM(const std::string& path) const
         }
         std::fwrite(row.data(), 1, row.size(), f);
     }
+    std::fclose(f);
+}
+
+// PNG, 8-bit RGB, scanlines unfiltered, the zlib stream made of stored blocks: every PNG reader accepts it and the writer needs
+// no compressor (an 8 MB frame becomes an 8 MB file; the viewer's frames are for looking at and for regression checks).
+void Renderer::writePNG(const std::string& path) const
+{
+    static uint32_t crcTable[256];
+    static bool haveTable = false;
+    if (!haveTable) {
+        for (uint32_t n = 0; n < 256; n++) {
+            uint32_t c = n;
+            for (int k = 0; k < 8; k++) c = (c & 1u) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+            crcTable[n] = c;
+        }
+        haveTable = true;
+    }
+    FILE* f = std::fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot write '" + path + "'");
+    auto be32 = [](uint8_t* p, uint32_t v) { p[0] = uint8_t(v >> 24); p[1] = uint8_t(v >> 16); p[2] = uint8_t(v >> 8); p[3] = uint8_t(v); };
+    auto chunk = [&](const char* type, const std::vector<uint8_t>& body) {
+        uint8_t head[8];
+        be32(head, static_cast<uint32_t>(body.size()));
+        std::memcpy(head + 4, type, 4);
+        uint32_t c = 0xFFFFFFFFu;
+        for (int i = 4; i < 8; i++) c = crcTable[(c ^ head[i]) & 255u] ^ (c >> 8);
+        for (uint8_t b : body) c = crcTable[(c ^ b) & 255u] ^ (c >> 8);
+        uint8_t tail[4];
+        be32(tail, c ^ 0xFFFFFFFFu);
+        std::fwrite(head, 1, 8, f);
+        if (!body.empty()) std::fwrite(body.data(), 1, body.size(), f);
+        std::fwrite(tail, 1, 4, f);
+    };
+    static const uint8_t magic[8] = { 0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A };
+    std::fwrite(magic, 1, 8, f);
+    std::vector<uint8_t> ihdr(13);
+    be32(ihdr.data(), width);
+    be32(ihdr.data() + 4, height);
+    ihdr[8] = 8; ihdr[9] = 2; ihdr[10] = 0; ihdr[11] = 0; ihdr[12] = 0; // 8 bits, RGB, deflate, filter method 0, not interlaced
+    chunk("IHDR", ihdr);
+    // raw image data: a filter byte (0) and 3 bytes per pixel for every scanline
+    std::vector<uint8_t> raw;
+    raw.reserve(static_cast<size_t>(height) * (1 + 3 * static_cast<size_t>(width)));
+    for (uint32_t y = 0; y < height; y++) {
+        raw.push_back(0);
+        const uint8_t* src = frame.data() + static_cast<size_t>(y) * width * 4;
+        for (uint32_t x = 0; x < width; x++) raw.insert(raw.end(), src + 4 * x, src + 4 * x + 3);
+    }
+    std::vector<uint8_t> z;
+    z.reserve(raw.size() + raw.size() / 65535 * 5 + 16);
+    z.push_back(0x78); z.push_back(0x01);
+    uint32_t a = 1, b = 0; // Adler-32 of the raw data
+    for (size_t at = 0; at < raw.size() || at == 0; at += 65535) {
+        const size_t n = std::min<size_t>(65535, raw.size() - at);
+        z.push_back(at + n >= raw.size() ? 1 : 0); // last block?
+        z.push_back(uint8_t(n)); z.push_back(uint8_t(n >> 8)); z.push_back(uint8_t(~n)); z.push_back(uint8_t((~n) >> 8));
+        z.insert(z.end(), raw.begin() + static_cast<std::ptrdiff_t>(at), raw.begin() + static_cast<std::ptrdiff_t>(at + n));
+        for (size_t i = at; i < at + n; i++) {
+            a = (a + raw[i]) % 65521u;
+            b = (b + a) % 65521u;
+        }
+        if (raw.empty()) break;
+    }
+    uint8_t adler[4];
+    be32(adler, (b << 16) | a);
+    z.insert(z.end(), adler, adler + 4);
+    chunk("IDAT", z);
+    chunk("IEND", {});
     std::fclose(f);
 }
 

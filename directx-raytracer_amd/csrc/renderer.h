@@ -40,6 +40,7 @@ public:
     uint32_t getFrameHeight() const { return height; }
     const std::vector<uint8_t>& getFrame() const { return frame; } // RGBA8, row-major, top-left origin
     void writePPM(const std::string& path) const;
+    void writePNG(const std::string& path) const; // 8-bit RGB, stored (uncompressed) deflate blocks
     const crt_frame_stats& getLastFrameStats() const { return stats; }
     void setCounting(bool on);
     void setOption(const char* name, int value); // crt_set_option: "spp", "max_bounces", "seed", "phong_ks", "phong_exponent", ...

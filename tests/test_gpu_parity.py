@@ -653,6 +653,36 @@ def test_headless_cpp_driver_matches_binding(pkg, oracle, scenes, dragon, tmp_pa
         assert raw[:header_end] == b"P6\n480 270\n255\n"
         img = np.frombuffer(raw[header_end:], dtype=np.uint8).reshape(270, 480, 3)
         np.testing.assert_array_equal(img, ref, err_msg="frame %d" % f)
+    # --png: the same frame as a PNG (8-bit RGB, stored deflate blocks -- several of them at this size), chunk CRCs and the
+    # Adler-32 checked by zlib, and readable by the product's own PNG decoder
+    import struct
+    import zlib
+    out = subprocess.run([exe, os.path.join(golden_dir, "dragon.crtscene"), "--mode", "100", "--size", "333x217", "--frames", "1",
+                          "--out", prefix, "--png"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    raw = open(prefix + "_0.png", "rb").read()
+    assert raw[:8] == b"\x89PNG\r\n\x1a\n"
+    at, idat, kinds = 8, b"", []
+    while at < len(raw):
+        n, kind = struct.unpack(">I4s", raw[at:at + 8])
+        body = raw[at + 8:at + 8 + n]
+        assert struct.unpack(">I", raw[at + 8 + n:at + 12 + n])[0] == zlib.crc32(kind + body), kind
+        kinds.append(kind)
+        if kind == b"IHDR":
+            assert struct.unpack(">IIBBBBB", body) == (333, 217, 8, 2, 0, 0, 0)
+        if kind == b"IDAT":
+            idat += body
+        at += 12 + n
+    assert kinds[0] == b"IHDR" and kinds[-1] == b"IEND"
+    lines = np.frombuffer(zlib.decompress(idat), dtype=np.uint8).reshape(217, 1 + 3 * 333)
+    assert not lines[:, 0].any()
+    s0 = pkg.Scene(os.path.join(golden_dir, "dragon.crtscene"))
+    pos, rot = s0.camera()
+    ref = O.render(pos, rot, 100, 333, 217)["rgba8"][..., :3]
+    np.testing.assert_array_equal(lines[:, 1:].reshape(217, 333, 3), ref)
+    t = pkg.Scene()
+    t.add_texture("frame", "bitmap", file_path=prefix + "_0.png")
+    np.testing.assert_array_equal(t.texture_color(0, 0.0, 1.0), ref[0, 0].astype(np.float32) / np.float32(255.0))
     # failure is an error message and a non-zero exit code, never an assert/abort
     bad = subprocess.run([exe, str(tmp_path / "nope.crtscene")], capture_output=True, text=True, timeout=60)
     assert bad.returncode == 1 and "cannot open" in bad.stderr
