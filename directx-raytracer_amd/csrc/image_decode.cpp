@@ -2,6 +2,8 @@
 #include "image_decode.h"
 
 #include <cstdint>
+#include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <stdexcept>
 
@@ -694,6 +696,176 @@ DecodedImage decodeGif(const std::vector<unsigned char>& f, const std::string& w
     }
 }
 
+// Radiance .hdr (RGBE, "#?RADIANCE" / "#?RGBE", FORMAT=32-bit_rle_rgbe, "-Y h +X w"), flat or run-length coded scanlines, turned
+// into three 8-bit channels the way the reference's stb_image does for stbi_load (R/stb_image/stb_image.h:1886-1912, 7241-7400):
+// value = mantissa * 2^(exponent - 136); byte = trunc(pow(value, 1 / 2.2f) * 255 + 0.5), clamped.  (pow in double precision from
+// the C library: the known answers come from the same library here; another platform's pow may round a texel differently.)
+DecodedImage decodeHdr(const std::vector<unsigned char>& f, const std::string& what)
+{
+    size_t at = 0;
+    auto eof = [&]() { return at >= f.size(); };
+    auto u8 = [&]() -> unsigned { return at < f.size() ? f[at++] : 0u; };
+    auto line = [&]() { // up to the next newline (at most 1023 characters are kept, the rest of the line is dropped)
+        std::string t;
+        unsigned c = u8();
+        while (!eof() && c != '\n') {
+            t.push_back(static_cast<char>(c));
+            if (t.size() == 1023) {
+                while (!eof() && u8() != '\n') {}
+                break;
+            }
+            c = u8();
+        }
+        return t;
+    };
+    const std::string magic = line();
+    if (magic != "#?RADIANCE" && magic != "#?RGBE") bad(what, "not a Radiance HDR file");
+    bool rgbe = false;
+    for (;;) {
+        const std::string t = line();
+        if (t.empty()) break;
+        if (t == "FORMAT=32-bit_rle_rgbe") rgbe = true;
+    }
+    if (!rgbe) bad(what, "HDR file that is not 32-bit_rle_rgbe");
+    const std::string dims = line();
+    char* rest = nullptr;
+    if (dims.compare(0, 3, "-Y ") != 0) bad(what, "HDR file with an unsupported scanline order");
+    const long h = std::strtol(dims.c_str() + 3, &rest, 10);
+    while (*rest == ' ') rest++;
+    if (std::strncmp(rest, "+X ", 3) != 0) bad(what, "HDR file with an unsupported scanline order");
+    const long w = std::strtol(rest + 3, nullptr, 10);
+    if (w <= 0 || h <= 0 || static_cast<uint64_t>(w) * static_cast<uint64_t>(h) > (1ull << 28)) bad(what, "HDR size missing or above 2^28 texels");
+    DecodedImage img;
+    img.width = static_cast<int>(w);
+    img.height = static_cast<int>(h);
+    img.channels = 3;
+    std::vector<float> lin(static_cast<size_t>(w) * h * 3, 0.0f);
+    auto convert = [&](float* out, const unsigned char* q) {
+        if (q[3] != 0) {
+            const float scale = static_cast<float>(std::ldexp(1.0f, static_cast<int>(q[3]) - (128 + 8)));
+            out[0] = q[0] * scale; out[1] = q[1] * scale; out[2] = q[2] * scale;
+        } else {
+            out[0] = out[1] = out[2] = 0.0f;
+        }
+    };
+    auto flatFrom = [&](size_t firstTexel) { // four bytes per texel, row after row
+        for (size_t t = firstTexel; t < static_cast<size_t>(w) * h; t++) {
+            unsigned char q[4];
+            for (int k = 0; k < 4; k++) q[k] = static_cast<unsigned char>(u8());
+            convert(lin.data() + 3 * t, q);
+        }
+    };
+    if (w < 8 || w >= 32768) {
+        flatFrom(0);
+    } else {
+        std::vector<unsigned char> scan(static_cast<size_t>(w) * 4);
+        for (long j = 0; j < h; j++) {
+            const unsigned c1 = u8(), c2 = u8(), hi = u8();
+            if (c1 != 2 || c2 != 2 || (hi & 0x80)) {
+                // not a run-length coded scanline: these four bytes are a texel, and that decoder goes on reading flat texels from
+                // the frame's SECOND texel whatever row it was in (so only a file that is flat from its first row decodes sensibly)
+                const unsigned char q[4] = { static_cast<unsigned char>(c1), static_cast<unsigned char>(c2), static_cast<unsigned char>(hi), static_cast<unsigned char>(u8()) };
+                convert(lin.data(), q);
+                flatFrom(1);
+                break;
+            }
+            if (static_cast<long>((hi << 8) | u8()) != w) bad(what, "HDR scanline of the wrong length");
+            for (int k = 0; k < 4; k++) {
+                long i = 0;
+                while (i < w) {
+                    unsigned count = u8();
+                    const bool run = count > 128;
+                    if (run) count -= 128;
+                    if (count == 0 || static_cast<long>(count) > w - i) bad(what, "damaged run-length data in an HDR file");
+                    const unsigned value = run ? u8() : 0u;
+                    for (unsigned z = 0; z < count; z++) scan[static_cast<size_t>(i++) * 4 + k] = static_cast<unsigned char>(run ? value : u8());
+                }
+            }
+            for (long i = 0; i < w; i++) convert(lin.data() + 3 * (static_cast<size_t>(j) * w + i), scan.data() + 4 * i);
+        }
+    }
+    img.pixels.resize(lin.size());
+    const float gammaInv = 1.0f / 2.2f, scaleInv = 1.0f;
+    for (size_t i = 0; i < lin.size(); i++) {
+        float z = static_cast<float>(std::pow(lin[i] * scaleInv, gammaInv)) * 255 + 0.5f;
+        if (z < 0) z = 0;
+        if (z > 255) z = 255;
+        img.pixels[i] = static_cast<unsigned char>(static_cast<int>(z));
+    }
+    return img;
+}
+
+// Photoshop .psd: the merged image of an 8- or 16-bit RGB file, raw or PackBits-coded planes, as four 8-bit channels (16-bit
+// samples reduced to their high byte, missing planes 0 / alpha 255); with an alpha plane the colours are un-matted from white
+// as the reference's stb_image does (R/stb_image/stb_image.h:6211-6390): c' = trunc(c / a + 255 (1 - 1 / a)) for 0 < alpha < 255.
+DecodedImage decodePsd(const std::vector<unsigned char>& f, const std::string& what)
+{
+    size_t at = 4;
+    auto u8 = [&]() -> unsigned { return at < f.size() ? f[at++] : (at++, 0u); };
+    auto u16 = [&]() -> unsigned { const unsigned hi = u8(); return (hi << 8) | u8(); };
+    auto u32 = [&]() -> uint32_t { const uint32_t hi = u16(); return (hi << 16) | u16(); };
+    auto skip = [&](uint64_t n) {
+        if (n > f.size() || at + n > f.size() + 16) bad(what, "PSD section runs past the end of the file");
+        at += static_cast<size_t>(n);
+    };
+    if (u16() != 1) bad(what, "PSD version that is not 1");
+    skip(6);
+    const unsigned channels = u16();
+    if (channels > 16) bad(what, "PSD with more than 16 channels");
+    const uint32_t h = u32(), w = u32();
+    const unsigned depth = u16();
+    if (depth != 8 && depth != 16) bad(what, "PSD bit depth that is not 8 or 16");
+    if (u16() != 3) bad(what, "PSD that is not in RGB mode");
+    skip(u32()); // colour mode data
+    skip(u32()); // image resources
+    skip(u32()); // layers and masks
+    const unsigned compression = u16();
+    if (compression > 1) bad(what, "PSD with an unknown compression");
+    if (w == 0 || h == 0 || static_cast<uint64_t>(w) * h > (1ull << 28)) bad(what, "PSD size missing or above 2^28 texels");
+    DecodedImage img;
+    img.width = static_cast<int>(w);
+    img.height = static_cast<int>(h);
+    img.channels = 4;
+    const size_t texels = static_cast<size_t>(w) * h;
+    img.pixels.assign(texels * 4, 0);
+    if (compression) skip(static_cast<uint64_t>(h) * channels * 2); // the byte counts of the coded rows: not needed, the planes are decoded as one stream
+    for (unsigned c = 0; c < 4; c++) {
+        unsigned char* p = img.pixels.data() + c;
+        if (c >= channels) {
+            for (size_t i = 0; i < texels; i++) p[4 * i] = c == 3 ? 255 : 0;
+        } else if (compression) { // PackBits over the whole plane
+            size_t done = 0;
+            while (done < texels) {
+                if (at >= f.size()) bad(what, "PSD plane ends early");
+                unsigned len = u8();
+                if (len == 128) continue;
+                if (len < 128) {
+                    len++;
+                    if (len > texels - done) bad(what, "damaged run-length data in a PSD file");
+                    for (unsigned k = 0; k < len; k++) p[4 * done++] = static_cast<unsigned char>(u8());
+                } else {
+                    len = 257 - len;
+                    if (len > texels - done) bad(what, "damaged run-length data in a PSD file");
+                    const unsigned v = u8();
+                    for (unsigned k = 0; k < len; k++) p[4 * done++] = static_cast<unsigned char>(v);
+                }
+            }
+        } else {
+            if (at >= f.size() && texels) bad(what, "PSD plane ends early");
+            for (size_t i = 0; i < texels; i++) p[4 * i] = static_cast<unsigned char>(depth == 16 ? (u16() >> 8) : u8());
+        }
+    }
+    if (channels >= 4)
+        for (size_t i = 0; i < texels; i++) {
+            unsigned char* px = img.pixels.data() + 4 * i;
+            if (px[3] != 0 && px[3] != 255) {
+                const float a = px[3] / 255.0f, ra = 1.0f / a, inv = 255.0f * (1 - ra);
+                for (int k = 0; k < 3; k++) px[k] = static_cast<unsigned char>(static_cast<int>(px[k] * ra + inv)); // (colours matted on white stay in 0..255)
+            }
+        }
+    return img;
+}
+
 bool endsWith(const std::string& s, const char* suffix)
 {
     const size_t n = std::strlen(suffix);
@@ -713,10 +885,12 @@ DecodedImage decodeImage(const std::vector<unsigned char>& f, const std::string&
     if (f.size() >= 8 && std::memcmp(f.data(), pngMagic, 8) == 0) return decodePng(f, what);
     if (f.size() >= 3 && f[0] == 0xFF && f[1] == 0xD8 && f[2] == 0xFF) return decodeJpeg(f, what);
     if (f.size() >= 6 && std::memcmp(f.data(), "GIF8", 4) == 0) return decodeGif(f, what);
+    if (f.size() >= 4 && std::memcmp(f.data(), "8BPS", 4) == 0) return decodePsd(f, what);
+    if ((f.size() >= 11 && std::memcmp(f.data(), "#?RADIANCE\n", 11) == 0) || (f.size() >= 7 && std::memcmp(f.data(), "#?RGBE\n", 7) == 0)) return decodeHdr(f, what);
     if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') return decodeBmp(f, what);
     if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) return decodePnm(f, what);
     if (endsWith(what, ".tga")) return decodeTga(f, what); // TGA has no magic number: by its name
-    bad(what, "not a PNG, JPEG, GIF, BMP, TGA or binary PPM / PGM file (PSD, HDR and PIC, which the reference's stb_image also reads, are not supported)");
+    bad(what, "not a PNG, JPEG, GIF, BMP, TGA, PSD, Radiance HDR or binary PPM / PGM file (Softimage PIC, which the reference's stb_image also reads, is not supported)");
 }
 
 } // namespace crt

@@ -70,7 +70,7 @@ def main():
     # 4) bitmap textures in the other formats the reference's stb_image reads and this repo decodes itself (csrc/image_decode.cpp):
     #    seeded images written here (PNG: every colour type, 1 / 4 / 8 / 16 bits, all five filters, stored / fixed / dynamic deflate
     #    blocks, Adam7; BMP: 24 / 32 bit, palette, top-down; TGA: raw / run-length, colour / grey; JPEG: baseline / progressive,
-    #    4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey, CMYK, restart intervals, one-texel edges), answers by CRTTextureBitmap
+    #    4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey, CMYK, restart intervals, one-texel edges; GIF; Radiance HDR; PSD), answers by CRTTextureBitmap
     answers = {}
     for name, data in bitmap_fixtures().items():
         path = os.path.join(gold, name)
@@ -343,6 +343,75 @@ def bitmap_fixtures():
     fx["tex_partial_bg.gif"] = raw_gif(9, 6, 3, tab8, 2, 1, 5, 3, rng.integers(0, 8, (3, 5)))
     fx["tex_partial_local_transparent.gif"] = raw_gif(9, 6, 2, tab8, 1, 1, 7, 4, rng.integers(0, 16, (4, 7)), local=loc16, transparent=6)
     fx["tex_partial_interlaced.gif"] = raw_gif(21, 19, 0, tab8, 3, 2, 15, 13, rng.integers(0, 8, (13, 15)), interlace=True)
+
+    # Radiance HDR: flat texels (narrow image), run-length coded scanlines (runs and literals in each of the four planes), and a
+    # wide image stored flat; exponents around 128 so that the tone curve's whole range is used
+    def hdr(wh, hh, coded, magic=b"#?RADIANCE"):
+        q = np.concatenate([rng.integers(0, 256, (hh, wh, 3)), rng.integers(120, 131, (hh, wh, 1))], -1).astype(np.uint8)
+        q[0, 0, 3] = 0  # an exponent of zero is black whatever the mantissas say
+        q[hh // 2, :, 3] = 127  # a row that compresses
+        q[hh // 2, : wh // 2, :3] = q[hh // 2, 0, :3]
+        out = bytearray(magic + b"\nEXPOSURE=1.0\nFORMAT=32-bit_rle_rgbe\n\n-Y %d +X %d\n" % (hh, wh))
+        for y in range(hh):
+            if not coded:
+                out += q[y].tobytes()
+                continue
+            out += bytes([2, 2, wh >> 8, wh & 255])
+            for k in range(4):
+                row, i = q[y, :, k], 0
+                while i < wh:
+                    run = 1
+                    while i + run < wh and run < 127 and row[i + run] == row[i]:
+                        run += 1
+                    if run >= 3:
+                        out += bytes([128 + run, int(row[i])])
+                        i += run
+                    else:
+                        lit = min(wh - i, 5)
+                        out += bytes([lit]) + row[i:i + lit].tobytes()
+                        i += lit
+        return bytes(out)
+    fx["tex_flat_narrow.hdr"] = hdr(7, 6, False)
+    fx["tex_rle.hdr"] = hdr(21, 19, True)
+    fx["tex_flat_wide.hdr"] = hdr(12, 5, False, magic=b"#?RGBE")
+
+    # Photoshop PSD (merged image): 8-bit raw RGB, 16-bit raw RGB, PackBits RGBA whose colours are matted on white
+    def psd(wp, hp, planes, depth=8, packbits=False):
+        out = bytearray(b"8BPS" + struct.pack(">H6xHIIHH", 1, len(planes), hp, wp, depth, 3) + struct.pack(">III", 0, 0, 0))
+        out += struct.pack(">H", 1 if packbits else 0)
+        if not packbits:
+            for pl in planes:
+                out += pl.astype(">u2" if depth == 16 else np.uint8).tobytes()
+            return bytes(out)
+        coded = []
+        for pl in planes:
+            for row in pl:
+                c, i = bytearray(), 0
+                while i < wp:
+                    run = 1
+                    while i + run < wp and run < 128 and row[i + run] == row[i]:
+                        run += 1
+                    if run >= 2:
+                        c += bytes([257 - run, int(row[i])])
+                        i += run
+                    else:
+                        lit = min(wp - i, 4)
+                        c += bytes([lit - 1]) + bytes(int(v) for v in row[i:i + lit])
+                        i += lit
+                coded.append(bytes(c))
+        out += b"".join(struct.pack(">H", len(c)) for c in coded) + b"".join(coded)
+        return bytes(out)
+    fx["tex_rgb8.psd"] = psd(9, 6, [rng.integers(0, 256, (6, 9)) for _ in range(3)])
+    fx["tex_rgb16.psd"] = psd(9, 6, [rng.integers(0, 65536, (6, 9)) for _ in range(3)], depth=16)
+    alpha = rng.integers(0, 256, (6, 9))
+    alpha[0, :3] = (0, 255, 128)
+    alpha[2, 2:7] = 200
+    matted = []
+    for _ in range(3):
+        colour = rng.integers(0, 256, (6, 9))
+        colour[2, 2:7] = colour[2, 2]
+        matted.append((colour * alpha + 255 * (255 - alpha) + 127) // 255)  # over white: the un-matting stays inside 0..255
+    fx["tex_rgba8_packbits.psd"] = psd(9, 6, matted + [alpha], packbits=True)
     return fx
 
 

@@ -246,9 +246,10 @@ def test_bitmap_formats_match_the_reference(pkg, golden_dir):
     or two texels wide -- a JPEG's texels depend on the decoder's inverse DCT, chroma filter and colour matrix, so these pin the
     arithmetic, not only the parsing; GIF (first image, four channels): global and local colour tables, interlaced, transparent
     index, an image smaller than its canvas with a background index (red and blue exchanged there, as the reference's decoder
-    leaves them)."""
+    leaves them); Radiance HDR flat and run-length coded through that decoder's tone curve; PSD 8 / 16 bit raw and PackBits RGBA
+    un-matted from white."""
     answers = json.load(open(os.path.join(golden_dir, "bitmap_known_answers.json")))
-    assert len(answers) >= 37 and sum(n.endswith(".jpg") for n in answers) >= 14 and sum(n.endswith(".gif") for n in answers) >= 6
+    assert len(answers) >= 43 and all(sum(n.endswith(e) for n in answers) >= k for e, k in ((".jpg", 14), (".gif", 6), (".hdr", 3), (".psd", 3)))
     f32 = np.float32
     for name, rows in sorted(answers.items()):
         s = pkg.Scene()
@@ -285,17 +286,24 @@ def test_damaged_bitmap_files_are_errors_not_crashes(pkg, golden_dir, tmp_path):
                 failed += 1
             path.unlink()
     assert tried > 1000 and failed > tried // 4
-    # formats the reference's stb_image reads and this decoder does not (PSD, HDR, PIC): a clear error naming them
-    psd = tmp_path / "x.psd"
-    psd.write_bytes(b"8BPS\0\1" + b"\0" * 64)
+    # the one format the reference's stb_image reads and this decoder does not (Softimage PIC): a clear error naming it
+    pic = tmp_path / "x.pic"
+    pic.write_bytes(b"\x53\x80\xf6\x34" + b"\0" * 84 + b"PICT" + b"\0" * 16)
     with pytest.raises(pkg.CrtError):
-        pkg.Scene().add_texture("b", "bitmap", file_path=str(psd))
-    scene = tmp_path / "psd.crtscene"
+        pkg.Scene().add_texture("b", "bitmap", file_path=str(pic))
+    scene = tmp_path / "pic.crtscene"
     scene.write_text('{"settings":{"background_color":[0,0,0],"image_settings":{"width":4,"height":4}},'
                      '"camera":{"matrix":[1,0,0,0,1,0,0,0,1],"position":[0,0,0]},"lights":[],"materials":[],'
-                     '"textures":[{"name":"t","type":"bitmap","file_path":"x.psd"}],"objects":[]}')
-    with pytest.raises(pkg.CrtError, match="PSD"):
+                     '"textures":[{"name":"t","type":"bitmap","file_path":"x.pic"}],"objects":[]}')
+    with pytest.raises(pkg.CrtError, match="PIC"):
         pkg.Scene(str(scene))
+    # a PSD in a colour mode other than RGB, an HDR in another pixel format
+    for name, blob in (("cmyk.psd", b"8BPS\0\1" + b"\0" * 6 + b"\0\4" + b"\0\0\0\2\0\0\0\2\0\x08\0\4" + b"\0" * 16),
+                       ("xyze.hdr", b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 2 +X 2\n" + b"\0" * 16)):
+        path = tmp_path / name
+        path.write_bytes(blob)
+        with pytest.raises(pkg.CrtError):
+            pkg.Scene().add_texture("b", "bitmap", file_path=str(path))
     # a GIF whose canvas has no extent, and one without any image
     for blob in (b"GIF89a" + b"\0" * 64, b"GIF89a\x02\x00\x02\x00\x00\x00\x00\x3B"):
         gif = tmp_path / "x.gif"
