@@ -866,6 +866,99 @@ DecodedImage decodePsd(const std::vector<unsigned char>& f, const std::string& w
     return img;
 }
 
+// Softimage .pic: 8-bit channels in up to ten packets per scanline (each naming its channels with a mask: 0x80 red .. 0x10 alpha),
+// raw, pure run-length or mixed run-length coded; three channels, or four when some packet carries alpha; channels no packet
+// carries are 255 (conventions of the reference's stb_image, R/stb_image/stb_image.h:6440-6590).
+DecodedImage decodePic(const std::vector<unsigned char>& f, const std::string& what)
+{
+    size_t at = 92;
+    auto need = [&]() { if (at >= f.size()) bad(what, "PIC file ends early"); };
+    auto u8 = [&]() -> unsigned { return at < f.size() ? f[at++] : (at++, 0u); };
+    auto u16 = [&]() -> unsigned { const unsigned hi = u8(); return (hi << 8) | u8(); };
+    if (f.size() < 104 || std::memcmp(f.data() + 88, "PICT", 4) != 0) bad(what, "not a Softimage PIC file");
+    const unsigned w = u16(), h = u16();
+    if (w == 0 || h == 0 || static_cast<uint64_t>(w) * h > (1ull << 28)) bad(what, "PIC size missing or above 2^28 texels");
+    at += 8; // ratio, fields, pad
+    struct Packet { unsigned type, mask; } packets[10];
+    int nPackets = 0;
+    unsigned all = 0, chained;
+    do {
+        if (nPackets == 10) bad(what, "PIC file with more than ten packets per scanline");
+        chained = u8();
+        const unsigned bits = u8();
+        packets[nPackets].type = u8();
+        packets[nPackets].mask = u8();
+        all |= packets[nPackets].mask;
+        nPackets++;
+        need();
+        if (bits != 8) bad(what, "PIC packet that is not 8 bits per channel");
+    } while (chained);
+    std::vector<unsigned char> rgba(static_cast<size_t>(w) * h * 4, 0xFF);
+    auto read = [&](unsigned mask, unsigned char* dest) {
+        for (int i = 0; i < 4; i++)
+            if (mask & (0x80u >> i)) {
+                need();
+                dest[i] = static_cast<unsigned char>(u8());
+            }
+    };
+    auto copy = [&](unsigned mask, unsigned char* dest, const unsigned char* src) {
+        for (int i = 0; i < 4; i++)
+            if (mask & (0x80u >> i)) dest[i] = src[i];
+    };
+    for (unsigned y = 0; y < h; y++)
+        for (int k = 0; k < nPackets; k++) {
+            const Packet& pk = packets[k];
+            unsigned char* dest = rgba.data() + static_cast<size_t>(y) * w * 4;
+            if (pk.type == 0) {
+                for (unsigned x = 0; x < w; x++, dest += 4) read(pk.mask, dest);
+            } else if (pk.type == 1) { // runs only; a run longer than the rest of the line is cut
+                unsigned left = w;
+                while (left > 0) {
+                    unsigned count = u8();
+                    need();
+                    if (count > left) count = left;
+                    unsigned char v[4] = { 0, 0, 0, 0 };
+                    read(pk.mask, v);
+                    for (unsigned i = 0; i < count; i++, dest += 4) copy(pk.mask, dest, v);
+                    left -= count;
+                    if (count == 0 && at >= f.size()) bad(what, "PIC file ends early");
+                }
+            } else if (pk.type == 2) { // runs (128: 16-bit length follows, above: length - 127) and literal stretches (below 128: length + 1)
+                unsigned left = w;
+                while (left > 0) {
+                    unsigned count = u8();
+                    need();
+                    if (count >= 128) {
+                        count = count == 128 ? u16() : count - 127;
+                        if (count > left) bad(what, "PIC run longer than its scanline");
+                        unsigned char v[4] = { 0, 0, 0, 0 };
+                        read(pk.mask, v);
+                        for (unsigned i = 0; i < count; i++, dest += 4) copy(pk.mask, dest, v);
+                        if (count == 0 && at >= f.size()) bad(what, "PIC file ends early");
+                    } else {
+                        count++;
+                        if (count > left) bad(what, "PIC run longer than its scanline");
+                        for (unsigned i = 0; i < count; i++, dest += 4) read(pk.mask, dest);
+                    }
+                    left -= count;
+                }
+            } else {
+                bad(what, "PIC packet with an unknown compression type");
+            }
+        }
+    DecodedImage img;
+    img.width = static_cast<int>(w);
+    img.height = static_cast<int>(h);
+    img.channels = (all & 0x10) ? 4 : 3;
+    if (img.channels == 4) {
+        img.pixels.swap(rgba);
+    } else {
+        img.pixels.resize(static_cast<size_t>(w) * h * 3);
+        for (size_t t = 0; t < static_cast<size_t>(w) * h; t++) std::memcpy(img.pixels.data() + 3 * t, rgba.data() + 4 * t, 3);
+    }
+    return img;
+}
+
 bool endsWith(const std::string& s, const char* suffix)
 {
     const size_t n = std::strlen(suffix);
@@ -886,11 +979,12 @@ DecodedImage decodeImage(const std::vector<unsigned char>& f, const std::string&
     if (f.size() >= 3 && f[0] == 0xFF && f[1] == 0xD8 && f[2] == 0xFF) return decodeJpeg(f, what);
     if (f.size() >= 6 && std::memcmp(f.data(), "GIF8", 4) == 0) return decodeGif(f, what);
     if (f.size() >= 4 && std::memcmp(f.data(), "8BPS", 4) == 0) return decodePsd(f, what);
+    if (f.size() >= 4 && std::memcmp(f.data(), "\x53\x80\xF6\x34", 4) == 0) return decodePic(f, what);
     if ((f.size() >= 11 && std::memcmp(f.data(), "#?RADIANCE\n", 11) == 0) || (f.size() >= 7 && std::memcmp(f.data(), "#?RGBE\n", 7) == 0)) return decodeHdr(f, what);
     if (f.size() >= 2 && f[0] == 'B' && f[1] == 'M') return decodeBmp(f, what);
     if (f.size() >= 2 && f[0] == 'P' && (f[1] == '5' || f[1] == '6')) return decodePnm(f, what);
     if (endsWith(what, ".tga")) return decodeTga(f, what); // TGA has no magic number: by its name
-    bad(what, "not a PNG, JPEG, GIF, BMP, TGA, PSD, Radiance HDR or binary PPM / PGM file (Softimage PIC, which the reference's stb_image also reads, is not supported)");
+    bad(what, "not a PNG, JPEG, GIF, BMP, TGA, PSD, Radiance HDR, Softimage PIC or binary PPM / PGM file");
 }
 
 } // namespace crt

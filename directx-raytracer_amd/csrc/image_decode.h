@@ -1,7 +1,7 @@
 // Bitmap texture files.  The reference loads whatever its vendored stb_image decodes (R/CRTTextureBitmap.cpp:10,
 // stbi_load(path, &w, &h, &channels, 0)); stb_image is third party and is not used here.  This decoder covers the formats a
 // .crtscene realistically names -- PNG (all colour types and bit depths, Adam7 interlace, tRNS), JPEG (baseline and progressive,
-// jpeg_decode.cpp), GIF (first image), Photoshop PSD (merged RGB image), Radiance HDR (through that decoder's tone curve), BMP (8-bit
+// jpeg_decode.cpp), GIF (first image), Photoshop PSD (merged RGB image), Radiance HDR (through that decoder's tone curve), Softimage PIC, BMP (8-bit
 // palette, 24 and 32 bit, uncompressed), TGA (true colour and grey, raw and run-length coded), binary
 // PPM / PGM -- and yields what stbi_load yields
 // for them: rows top to bottom, `channels` bytes per texel in the file's own channel count (1 grey, 2 grey + alpha, 3 RGB,

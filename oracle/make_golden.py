@@ -70,7 +70,7 @@ def main():
     # 4) bitmap textures in the other formats the reference's stb_image reads and this repo decodes itself (csrc/image_decode.cpp):
     #    seeded images written here (PNG: every colour type, 1 / 4 / 8 / 16 bits, all five filters, stored / fixed / dynamic deflate
     #    blocks, Adam7; BMP: 24 / 32 bit, palette, top-down; TGA: raw / run-length, colour / grey; JPEG: baseline / progressive,
-    #    4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey, CMYK, restart intervals, one-texel edges; GIF; Radiance HDR; PSD), answers by CRTTextureBitmap
+    #    4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey, CMYK, restart intervals, one-texel edges; GIF; Radiance HDR; PSD; Softimage PIC), answers by CRTTextureBitmap
     answers = {}
     for name, data in bitmap_fixtures().items():
         path = os.path.join(gold, name)
@@ -412,6 +412,49 @@ def bitmap_fixtures():
         colour[2, 2:7] = colour[2, 2]
         matted.append((colour * alpha + 255 * (255 - alpha) + 127) // 255)  # over white: the un-matting stays inside 0..255
     fx["tex_rgba8_packbits.psd"] = psd(9, 6, matted + [alpha], packbits=True)
+
+    # Softimage PIC: raw RGB; mixed run-length RGB chained to a pure run-length alpha packet; long 16-bit runs
+    def pic(wq, hq, packets, rows):
+        out = bytearray(b"\x53\x80\xF6\x34" + struct.pack(">f", 3.71) + b"seeded".ljust(80, b"\0") + b"PICT" + struct.pack(">HHfHH", wq, hq, 1.0, 3, 0))
+        for i, (kind, mask) in enumerate(packets):
+            out += bytes([1 if i + 1 < len(packets) else 0, 8, kind, mask])
+        for y in range(hq):
+            for (kind, mask), line in zip(packets, rows):
+                px = [bytes(int(v) for v in t) for t in line[y]]  # per texel: the bytes of the packet's channels, in R G B A order
+                if kind == 0:
+                    out += b"".join(px)
+                    continue
+                i = 0
+                while i < wq:
+                    run = 1
+                    while i + run < wq and px[i + run] == px[i] and run < (255 if kind == 1 else 400):
+                        run += 1
+                    if kind == 1:
+                        out += bytes([run]) + px[i]
+                        i += run
+                    elif run >= 130:
+                        out += bytes([128]) + struct.pack(">H", run) + px[i]
+                        i += run
+                    elif run >= 2:
+                        out += bytes([127 + run]) + px[i]
+                        i += run
+                    else:
+                        lit = min(wq - i, 3)
+                        out += bytes([lit - 1]) + b"".join(px[i:i + lit])
+                        i += lit
+        return bytes(out)
+    rgbp = rng.integers(0, 256, (6, 9, 3))
+    fx["tex_raw.pic"] = pic(9, 6, [(0, 0xE0)], [rgbp])
+    rgbq = rng.integers(0, 256, (6, 9, 3))
+    rgbq[1:4, 2:8] = rgbq[1, 2]
+    alq = rng.integers(0, 256, (6, 9, 1))
+    alq[:, 3:7] = 77
+    fx["tex_mixed_alpha.pic"] = pic(9, 6, [(2, 0xE0), (1, 0x10)], [rgbq, alq])
+    wide = np.zeros((3, 300, 3), dtype=np.int64)
+    wide[:, :, 0] = (np.arange(300) // 150) * 200
+    wide[:, :, 1] = rng.integers(0, 256, (3, 1))
+    wide[1, 290:, 2] = rng.integers(0, 256, 10)
+    fx["tex_long_runs.pic"] = pic(300, 3, [(2, 0xE0)], [wide])
     return fx
 
 

@@ -247,9 +247,10 @@ def test_bitmap_formats_match_the_reference(pkg, golden_dir):
     arithmetic, not only the parsing; GIF (first image, four channels): global and local colour tables, interlaced, transparent
     index, an image smaller than its canvas with a background index (red and blue exchanged there, as the reference's decoder
     leaves them); Radiance HDR flat and run-length coded through that decoder's tone curve; PSD 8 / 16 bit raw and PackBits RGBA
-    un-matted from white."""
+    un-matted from white; Softimage PIC raw, mixed and pure run-length packets with and without alpha, 16-bit run lengths.
+    With these every format the reference's loader accepts is read here."""
     answers = json.load(open(os.path.join(golden_dir, "bitmap_known_answers.json")))
-    assert len(answers) >= 43 and all(sum(n.endswith(e) for n in answers) >= k for e, k in ((".jpg", 14), (".gif", 6), (".hdr", 3), (".psd", 3)))
+    assert len(answers) >= 46 and all(sum(n.endswith(e) for n in answers) >= k for e, k in ((".jpg", 14), (".gif", 6), (".hdr", 3), (".psd", 3), (".pic", 3)))
     f32 = np.float32
     for name, rows in sorted(answers.items()):
         s = pkg.Scene()
@@ -286,17 +287,22 @@ def test_damaged_bitmap_files_are_errors_not_crashes(pkg, golden_dir, tmp_path):
                 failed += 1
             path.unlink()
     assert tried > 1000 and failed > tried // 4
-    # the one format the reference's stb_image reads and this decoder does not (Softimage PIC): a clear error naming it
+    # a format nobody reads here (the reference's stb_image neither): a clear error naming the ones that are
+    webp = tmp_path / "x.webp"
+    webp.write_bytes(b"RIFF\x20\0\0\0WEBPVP8 " + b"\0" * 32)
+    with pytest.raises(pkg.CrtError):
+        pkg.Scene().add_texture("b", "bitmap", file_path=str(webp))
+    scene = tmp_path / "webp.crtscene"
+    scene.write_text('{"settings":{"background_color":[0,0,0],"image_settings":{"width":4,"height":4}},'
+                     '"camera":{"matrix":[1,0,0,0,1,0,0,0,1],"position":[0,0,0]},"lights":[],"materials":[],'
+                     '"textures":[{"name":"t","type":"bitmap","file_path":"x.webp"}],"objects":[]}')
+    with pytest.raises(pkg.CrtError, match="not a PNG, JPEG, GIF, BMP, TGA, PSD, Radiance HDR, Softimage PIC"):
+        pkg.Scene(str(scene))
+    # a PIC without an extent
     pic = tmp_path / "x.pic"
     pic.write_bytes(b"\x53\x80\xf6\x34" + b"\0" * 84 + b"PICT" + b"\0" * 16)
     with pytest.raises(pkg.CrtError):
         pkg.Scene().add_texture("b", "bitmap", file_path=str(pic))
-    scene = tmp_path / "pic.crtscene"
-    scene.write_text('{"settings":{"background_color":[0,0,0],"image_settings":{"width":4,"height":4}},'
-                     '"camera":{"matrix":[1,0,0,0,1,0,0,0,1],"position":[0,0,0]},"lights":[],"materials":[],'
-                     '"textures":[{"name":"t","type":"bitmap","file_path":"x.pic"}],"objects":[]}')
-    with pytest.raises(pkg.CrtError, match="PIC"):
-        pkg.Scene(str(scene))
     # a PSD in a colour mode other than RGB, an HDR in another pixel format
     for name, blob in (("cmyk.psd", b"8BPS\0\1" + b"\0" * 6 + b"\0\4" + b"\0\0\0\2\0\0\0\2\0\x08\0\4" + b"\0" * 16),
                        ("xyze.hdr", b"#?RADIANCE\nFORMAT=32-bit_rle_xyze\n\n-Y 2 +X 2\n" + b"\0" * 16)):
