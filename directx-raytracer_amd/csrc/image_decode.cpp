@@ -2,6 +2,7 @@
 #include "image_decode.h"
 
 #include <cstdint>
+#include <algorithm>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -377,14 +378,32 @@ DecodedImage decodeBmp(const std::vector<unsigned char>& f, const std::string& w
     const bool flip = h > 0; // rows bottom-up unless the height is negative
     if (h < 0) h = -h;
     if (w <= 0 || h <= 0 || w * h > kMaxTexels) bad(what, "bad BMP size");
-    if (compression != 0 && !(compression == 3 && (bpp == 32))) bad(what, "compressed BMP files are not supported");
-    uint32_t mr = 0x00FF0000u, mg = 0x0000FF00u, mb = 0x000000FFu, ma = 0xFF000000u;
-    if (compression == 3) {
-        const size_t maskAt = 14 + 40;
-        if (maskAt + 12 > f.size()) bad(what, "BMP file too short");
-        mr = le32(&f[maskAt]); mg = le32(&f[maskAt + 4]); mb = le32(&f[maskAt + 8]);
-        ma = (hsz >= 56 && maskAt + 16 <= f.size()) ? le32(&f[maskAt + 12]) : 0u;
-        if (mr != 0x00FF0000u || mg != 0x0000FF00u || mb != 0x000000FFu || (ma != 0u && ma != 0xFF000000u)) bad(what, "BMP channel masks other than 8-8-8-8 BGRA are not supported");
+    if (compression == 1 || compression == 2) bad(what, "run-length coded BMP files are not supported (the reference's decoder rejects them too)");
+    if (compression >= 4) bad(what, "BMP files that wrap a JPEG or PNG are not supported (the reference's decoder rejects them too)");
+    if (compression == 3 && bpp != 16 && bpp != 32) bad(what, "BMP channel masks need 16 or 32 bits per pixel");
+    // channel masks, as the reference's decoder settles them (R/stb_image/stb_image.h:5484-5597): 16 bits default to 5-5-5, 32 bits
+    // to 8-8-8-8 BGRA; BI_BITFIELDS files carry their own -- behind a 40-byte header (and, as that decoder has it, behind a 56-byte
+    // one too, whose own mask fields it skips), or in the V4 / V5 header, where they only count in BI_BITFIELDS mode
+    uint32_t mr = 0, mg = 0, mb = 0, ma = 0;
+    bool alphaMayBeUnused = false; // 32-bit default masks: an alpha channel that is zero everywhere means "no alpha"
+    auto defaults = [&]() {
+        if (bpp == 16) { mr = 31u << 10; mg = 31u << 5; mb = 31u; }
+        else if (bpp == 32) { mr = 0x00FF0000u; mg = 0x0000FF00u; mb = 0x000000FFu; ma = 0xFF000000u; alphaMayBeUnused = true; }
+        else { mr = mg = mb = ma = 0; }
+    };
+    if (hsz == 40 || hsz == 56) {
+        if (bpp == 16 || bpp == 32) {
+            if (compression == 0) defaults();
+            else {
+                const size_t maskAt = 14 + static_cast<size_t>(hsz);
+                if (maskAt + 12 > f.size()) bad(what, "BMP file too short");
+                mr = le32(&f[maskAt]); mg = le32(&f[maskAt + 4]); mb = le32(&f[maskAt + 8]);
+                if (mr == mg && mg == mb) bad(what, "BMP channel masks that are all the same");
+            }
+        }
+    } else if (hsz == 108 || hsz == 124) {
+        mr = le32(&f[14 + 40]); mg = le32(&f[14 + 44]); mb = le32(&f[14 + 48]); ma = le32(&f[14 + 52]);
+        if (compression != 3) defaults();
     }
     DecodedImage img;
     img.width = static_cast<int>(w);
@@ -412,86 +431,158 @@ DecodedImage decodeBmp(const std::vector<unsigned char>& f, const std::string& w
         }
         return img;
     }
-    if (bpp != 24 && bpp != 32) bad(what, "BMP files of this bit depth are not supported");
+    if (bpp != 16 && bpp != 24 && bpp != 32) bad(what, "BMP files of this bit depth are not supported");
     const size_t bytes = bpp / 8, stride = ((W * bpp + 31) / 32) * 4;
     if (dataOffset > f.size() || stride * H > f.size() - dataOffset) bad(what, "BMP pixel data runs past the end of the file");
-    img.channels = bpp == 32 ? 4 : 3;
+    img.channels = (bpp == 24 && ma == 0xFF000000u) ? 3 : (ma ? 4 : 3);
     img.pixels.resize(W * H * img.channels);
-    bool anyAlpha = false;
+    const bool bgr = bpp == 24, bgra = bpp == 32 && mb == 0xFFu && mg == 0xFF00u && mr == 0x00FF0000u && ma == 0xFF000000u;
+    if (bgr || bgra) {
+        bool anyAlpha = false;
+        for (size_t y = 0; y < H; y++) {
+            const unsigned char* line = &f[dataOffset + (flip ? H - 1 - y : y) * stride];
+            for (size_t x = 0; x < W; x++) {
+                const unsigned char* s = line + x * bytes;
+                unsigned char* dst = &img.pixels[(y * W + x) * img.channels];
+                dst[0] = s[2]; dst[1] = s[1]; dst[2] = s[0];
+                if (img.channels == 4) {
+                    dst[3] = bgra ? s[3] : 255;
+                    anyAlpha = anyAlpha || (bgra && s[3] != 0);
+                }
+            }
+        }
+        if (bgra && alphaMayBeUnused && !anyAlpha) // (stb_image does the same)
+            for (size_t i = 0; i < W * H; i++) img.pixels[i * 4 + 3] = 255;
+        return img;
+    }
+    // any other masks: a channel's bits are moved to the top of a byte and the byte is filled by repeating them
+    if (!mr || !mg || !mb) bad(what, "BMP without channel masks");
+    auto highBit = [](uint32_t z) { int n = -1; while (z) { n++; z >>= 1; } return n; };
+    auto bitCount = [](uint32_t z) { int n = 0; while (z) { n += static_cast<int>(z & 1u); z >>= 1; } return n; };
+    const uint32_t mask[4] = { mr, mg, mb, ma };
+    int shift[4], count[4];
+    for (int k = 0; k < 4; k++) {
+        shift[k] = highBit(mask[k]) - 7;
+        count[k] = bitCount(mask[k]);
+        if (count[k] > 8) bad(what, "BMP channel mask wider than 8 bits");
+    }
+    auto widen = [](uint32_t v, int shiftBy, int bits) -> unsigned char {
+        static const unsigned mul[9] = { 0, 0xFF, 0x55, 0x49, 0x11, 0x21, 0x41, 0x81, 0x01 };
+        static const unsigned down[9] = { 0, 0, 0, 1, 0, 2, 4, 6, 0 };
+        v = shiftBy < 0 ? v << -shiftBy : v >> shiftBy;
+        v = (v & 0xFFu) >> (8 - bits); // (a mask whose bits are not contiguous leaves stray bits above: only the byte counts)
+        return static_cast<unsigned char>((v * mul[bits]) >> down[bits]);
+    };
     for (size_t y = 0; y < H; y++) {
         const unsigned char* line = &f[dataOffset + (flip ? H - 1 - y : y) * stride];
         for (size_t x = 0; x < W; x++) {
-            const unsigned char* s = line + x * bytes;
+            const uint32_t v = bpp == 16 ? le16(line + 2 * x) : le32(line + 4 * x);
             unsigned char* dst = &img.pixels[(y * W + x) * img.channels];
-            dst[0] = s[2]; dst[1] = s[1]; dst[2] = s[0];
-            if (bpp == 32) {
-                dst[3] = ma ? s[3] : 255;
-                anyAlpha = anyAlpha || s[3] != 0;
-            }
+            for (int k = 0; k < 3; k++) dst[k] = widen(v & mask[k], shift[k], count[k]);
+            if (img.channels == 4) dst[3] = widen(v & ma, shift[3], count[3]);
         }
     }
-    if (bpp == 32 && ma && !anyAlpha) // an alpha channel that is zero everywhere means "no alpha": opaque (stb_image does the same)
-        for (size_t i = 0; i < W * H; i++) img.pixels[i * 4 + 3] = 255;
     return img;
 }
 
 // ---------------------------------------------------------------------------------------------- TGA
 DecodedImage decodeTga(const std::vector<unsigned char>& f, const std::string& what)
 {
+    // Truevision TGA as the reference's decoder reads it (R/stb_image/stb_image.h, stbi__tga_load): true colour 24 / 32 bits, 15 / 16
+    // bits (5-5-5, scaled c * 255 / 31, no alpha), grey 8 bits, grey + alpha 16 bits, colour-mapped with 8- or 16-bit indices into a
+    // palette of any of those entry sizes; raw or run-length coded; bottom-up unless descriptor bit 5 is set (bit 4, right-to-left,
+    // is ignored there and here); an index outside the palette reads entry 0; the palette's "first entry" field is skipped as BYTES.
     if (f.size() < 18) bad(what, "TGA file too short");
-    const int idLen = f[0], cmapType = f[1], type = f[2], bpp = f[16], descriptor = f[17];
+    const unsigned idLen = f[0], mapped = f[1], palStart = le16(&f[3]), palLen = le16(&f[5]), palBits = f[7];
     const size_t w = le16(&f[12]), h = le16(&f[14]);
-    if (cmapType != 0 || (type != 2 && type != 3 && type != 10 && type != 11)) bad(what, "only true-colour and grey TGA files (types 2, 3, 10, 11) are supported");
-    const bool grey = type == 3 || type == 11, rle = type >= 10;
-    if ((grey && bpp != 8) || (!grey && bpp != 24 && bpp != 32)) bad(what, "TGA files of this bit depth are not supported");
+    const unsigned bpp = f[16], descriptor = f[17];
+    unsigned type = f[2];
+    const bool rle = type >= 8;
+    if (rle) type -= 8;
+    if (mapped > 1) bad(what, "TGA colour-map type that is not 0 or 1");
+    if (mapped ? type != 1 : (type != 2 && type != 3)) bad(what, "TGA image type that is not colour-mapped, true colour or grey");
+    if (mapped && bpp != 8 && bpp != 16) bad(what, "colour-mapped TGA whose indices are not 8 or 16 bits");
     if (w == 0 || h == 0) bad(what, "bad TGA size");
-    const size_t bytes = static_cast<size_t>(bpp) / 8, n = w * h;
+    auto layout = [&](unsigned bits, bool grey, bool& packed555) -> unsigned { // bytes per texel of the result
+        packed555 = false;
+        if (bits == 8) return 1;
+        if (bits == 16 && grey) return 2;
+        if (bits == 15 || bits == 16) { packed555 = true; return 3; }
+        if (bits == 24 || bits == 32) return bits / 8;
+        bad(what, "TGA files of this bit depth are not supported");
+    };
+    bool packed = false;
+    const unsigned comp = mapped ? layout(palBits, false, packed) : layout(bpp, type == 3, packed);
+    const size_t n = w * h;
     size_t pos = 18 + static_cast<size_t>(idLen);
-    std::vector<unsigned char> raw(n * bytes);
-    if (!rle) {
-        if (pos > f.size() || raw.size() > f.size() - pos) bad(what, "TGA pixel data runs past the end of the file");
-        std::memcpy(raw.data(), &f[pos], raw.size());
-    } else {
-        size_t i = 0;
-        while (i < n) {
-            if (pos >= f.size()) bad(what, "TGA run-length data ends early");
-            const int head = f[pos++];
-            const size_t count = static_cast<size_t>(head & 127) + 1;
-            if (i + count > n) bad(what, "TGA run crosses the end of the image");
-            if (head & 128) {
-                if (pos + bytes > f.size()) bad(what, "TGA run-length data ends early");
-                for (size_t k = 0; k < count; k++) std::memcpy(&raw[(i + k) * bytes], &f[pos], bytes);
-                pos += bytes;
-            } else {
-                if (pos + count * bytes > f.size()) bad(what, "TGA run-length data ends early");
-                std::memcpy(&raw[i * bytes], &f[pos], count * bytes);
-                pos += count * bytes;
-            }
-            i += count;
+    auto need = [&](size_t bytes) { if (pos > f.size() || bytes > f.size() - pos) bad(what, "TGA data runs past the end of the file"); };
+    auto rgb555 = [&](unsigned char* out) {
+        need(2);
+        const unsigned px = le16(&f[pos]);
+        pos += 2;
+        out[0] = static_cast<unsigned char>((((px >> 10) & 31u) * 255u) / 31u);
+        out[1] = static_cast<unsigned char>((((px >> 5) & 31u) * 255u) / 31u);
+        out[2] = static_cast<unsigned char>(((px & 31u) * 255u) / 31u);
+    };
+    std::vector<unsigned char> palette;
+    if (mapped) {
+        if (palLen == 0) bad(what, "colour-mapped TGA without a palette");
+        need(palStart);
+        pos += palStart;
+        palette.resize(static_cast<size_t>(palLen) * comp);
+        if (packed) {
+            for (unsigned i = 0; i < palLen; i++) rgb555(&palette[static_cast<size_t>(i) * comp]);
+        } else {
+            need(palette.size());
+            std::memcpy(palette.data(), &f[pos], palette.size());
+            pos += palette.size();
         }
     }
     DecodedImage img;
     img.width = static_cast<int>(w);
     img.height = static_cast<int>(h);
-    img.channels = static_cast<int>(bytes);
-    img.pixels.resize(n * bytes);
-    const bool topDown = (descriptor >> 5) & 1, rightLeft = (descriptor >> 4) & 1;
-    for (size_t y = 0; y < h; y++) {
-        const size_t sy = topDown ? y : h - 1 - y;
-        for (size_t x = 0; x < w; x++) {
-            const unsigned char* s = &raw[(sy * w + (rightLeft ? w - 1 - x : x)) * bytes];
-            unsigned char* dst = &img.pixels[(y * w + x) * bytes];
-            if (grey) dst[0] = s[0];
-            else {
-                dst[0] = s[2]; dst[1] = s[1]; dst[2] = s[0];
-                if (bytes == 4) dst[3] = s[3];
+    img.channels = static_cast<int>(comp);
+    img.pixels.resize(n * comp);
+    unsigned char texel[4] = { 0, 0, 0, 0 };
+    unsigned left = 0;       // texels left in the current packet
+    bool repeating = false;  // ... which repeats `texel`
+    for (size_t i = 0; i < n; i++) {
+        bool readOne = true;
+        if (rle) {
+            if (left == 0) {
+                need(1);
+                const unsigned head = f[pos++];
+                left = 1 + (head & 127u);
+                repeating = (head >> 7) != 0;
+            } else if (repeating) {
+                readOne = false;
             }
         }
+        if (readOne) {
+            if (mapped) {
+                need(bpp / 8);
+                size_t idx = bpp == 8 ? f[pos] : le16(&f[pos]);
+                pos += bpp / 8;
+                if (idx >= palLen) idx = 0;
+                std::memcpy(texel, &palette[idx * comp], comp);
+            } else if (packed) {
+                rgb555(texel);
+            } else {
+                need(comp);
+                std::memcpy(texel, &f[pos], comp);
+                pos += comp;
+            }
+        }
+        std::memcpy(&img.pixels[i * comp], texel, comp);
+        if (rle) left--;
     }
+    if (!((descriptor >> 5) & 1u)) // stored bottom-up
+        for (size_t y = 0; y * 2 < h; y++)
+            for (size_t x = 0; x < w * comp; x++) std::swap(img.pixels[y * w * comp + x], img.pixels[(h - 1 - y) * w * comp + x]);
+    if (comp >= 3 && !packed) // stored blue first
+        for (size_t i = 0; i < n; i++) std::swap(img.pixels[i * comp], img.pixels[i * comp + 2]);
     return img;
 }
-
-// ---------------------------------------------------------------------------------------------- binary PPM / PGM
 DecodedImage decodePnm(const std::vector<unsigned char>& f, const std::string& what)
 {
     size_t pos = 2;
@@ -518,14 +609,17 @@ DecodedImage decodePnm(const std::vector<unsigned char>& f, const std::string& w
     };
     const long long w = nextInt(), h = nextInt(), maxv = nextInt();
     pos++; // the single whitespace byte after maxval
-    if (w <= 0 || h <= 0 || maxv != 255 || w * h > kMaxTexels) bad(what, "bad PNM header");
+    if (w <= 0 || h <= 0 || maxv > 65535 || w * h > kMaxTexels) bad(what, "bad PNM header");
     DecodedImage img;
     img.width = static_cast<int>(w);
     img.height = static_cast<int>(h);
     img.channels = f[1] == '6' ? 3 : 1;
-    const size_t bytes = static_cast<size_t>(w) * h * img.channels;
+    // samples are taken as they are, whatever the maximum says; above 255 they are two bytes each, of which the reference's decoder
+    // keeps the SECOND (it reads the big-endian pairs as host-order words on a little-endian machine and keeps the word's high byte)
+    const size_t wide = maxv > 255 ? 2 : 1, samples = static_cast<size_t>(w) * h * img.channels, bytes = samples * wide;
     if (pos > f.size() || bytes > f.size() - pos) bad(what, "truncated");
-    img.pixels.assign(f.begin() + static_cast<long>(pos), f.begin() + static_cast<long>(pos + bytes));
+    img.pixels.resize(samples);
+    for (size_t i = 0; i < samples; i++) img.pixels[i] = f[pos + i * wide + (wide - 1)];
     return img;
 }
 

@@ -1,12 +1,12 @@
 // Bitmap texture files.  The reference loads whatever its vendored stb_image decodes (R/CRTTextureBitmap.cpp:10,
-// stbi_load(path, &w, &h, &channels, 0)); stb_image is third party and is not used here.  This decoder covers the formats a
-// .crtscene realistically names -- PNG (all colour types and bit depths, Adam7 interlace, tRNS), JPEG (baseline and progressive,
-// jpeg_decode.cpp), GIF (first image), Photoshop PSD (merged RGB image), Radiance HDR (through that decoder's tone curve), Softimage PIC, BMP (8-bit
-// palette, 24 and 32 bit, uncompressed), TGA (true colour and grey, raw and run-length coded), binary
-// PPM / PGM -- and yields what stbi_load yields
-// for them: rows top to bottom, `channels` bytes per texel in the file's own channel count (1 grey, 2 grey + alpha, 3 RGB,
-// 4 RGBA; 16-bit samples reduced to their high byte).  Known answers: tests/golden/texture_known_answers.json, produced by the
-// reference's own CRTTextureBitmap over the same files (oracle/make_golden.py).
+// stbi_load(path, &w, &h, &channels, 0)); stb_image is third party and is not used here.  These decoders cover every format it
+// reads -- PNG (all colour types and bit depths, Adam7 interlace, tRNS), JPEG (baseline and progressive, jpeg_decode.cpp), GIF
+// (first image), Photoshop PSD (merged RGB image), Radiance HDR (through that decoder's tone curve), Softimage PIC, BMP (palettes,
+// 16 / 24 / 32 bit with channel masks, uncompressed), TGA (true colour, grey, colour-mapped; raw and run-length coded), binary
+// PPM / PGM -- and yield what stbi_load yields for them, that decoder's oddities included where a texel depends on them: rows top
+// to bottom, `channels` bytes per texel in the file's own channel count (1 grey, 2 grey + alpha, 3 RGB, 4 RGBA; 16-bit PNG / PSD
+// samples reduced to their high byte).  Known answers: tests/golden/bitmap_known_answers.json, produced by the reference's own
+// CRTTextureBitmap over the same 61 files (oracle/make_golden.py).
 #pragma once
 
 #include <string>

@@ -169,7 +169,7 @@ def _png(w, h, depth, color, rows, level=9, strategy=None, interlace=False, pale
 
 
 ONE_CHANNEL = {"tex_grey8_stored.png": (9, 6), "tex_grey1.png": (13, 6), "tex_grey8.tga": (9, 6), "tex_grey.jpg": (21, 19),
-               "tex_proggrey.jpg": (20, 21)}  # name -> (width, height)
+               "tex_proggrey.jpg": (20, 21), "tex_max65535.pgm": (9, 6)}  # name -> (width, height)
 
 
 def bitmap_fixtures():
@@ -455,6 +455,67 @@ def bitmap_fixtures():
     wide[:, :, 1] = rng.integers(0, 256, (3, 1))
     wide[1, 290:, 2] = rng.integers(0, 256, 10)
     fx["tex_long_runs.pic"] = pic(300, 3, [(2, 0xE0)], [wide])
+
+    # BMP with 16 bits per pixel and with channel masks (BI_BITFIELDS): 5-5-5 by default, 5-6-5 and 8-bit fields at odd places behind
+    # a 40-byte header, 4-4-4-4 with alpha in a V4 header; 4-bit and 1-bit palettes
+    def bmp_masks(wb, hb, bpp, words, masks=None, v4_alpha=None):
+        stride = ((wb * bpp + 31) // 32) * 4
+        body = b"".join(struct.pack("<%d%s" % (wb, "H" if bpp == 16 else "I"), *[int(v) for v in row]).ljust(stride, b"\0") for row in words[::-1])
+        if v4_alpha is not None:
+            dib = struct.pack("<IiiHHIIiiII", 108, wb, hb, 1, bpp, 3, len(body), 2835, 2835, 0, 0) + struct.pack("<IIII", *masks, v4_alpha) + b"BGRs" + b"\0" * 48
+            extra = b""
+        else:
+            dib = struct.pack("<IiiHHIIiiII", 40, wb, hb, 1, bpp, 3 if masks else 0, len(body), 2835, 2835, 0, 0)
+            extra = struct.pack("<III", *masks) if masks else b""
+        off = 14 + len(dib) + len(extra)
+        return b"BM" + struct.pack("<IHHI", off + len(body), 0, 0, off) + dib + extra + body
+    fx["tex_555.bmp"] = bmp_masks(w, h, 16, rng.integers(0, 1 << 15, (h, w)))
+    fx["tex_565.bmp"] = bmp_masks(w, h, 16, rng.integers(0, 1 << 16, (h, w)), masks=(0xF800, 0x07E0, 0x001F))
+    fx["tex_odd_masks32.bmp"] = bmp_masks(w, h, 32, rng.integers(0, 1 << 32, (h, w), dtype=np.uint64), masks=(0x3FC00000, 0x000FE000, 0x000000E0))
+    fx["tex_4444_v4.bmp"] = bmp_masks(w, h, 16, rng.integers(0, 1 << 16, (h, w)), masks=(0x0F00, 0x00F0, 0x000F), v4_alpha=0xF000)
+    pal16 = [tuple(int(x) for x in c) for c in rng.integers(0, 256, (16, 3))]
+    idx4 = rng.integers(0, 16, (h, w))
+    fx["tex_pal4.bmp"] = bmp(w, h, 4, [bytes((int(r[i]) << 4) | (int(r[i + 1]) if i + 1 < w else 0) for i in range(0, w, 2)) for r in idx4], palette=pal16)
+    bits1 = rng.integers(0, 2, (h, 13))
+    fx["tex_pal1.bmp"] = bmp(13, h, 1, [bytes(np.packbits(r).tolist()) for r in bits1], palette=pal16[:2])
+
+    # TGA beyond true colour: colour-mapped (8-bit indices into 24-bit entries, one index outside the palette; run-length coded
+    # 16-bit indices into 5-5-5 entries behind a "first entry" field), 16-bit 5-5-5 true colour, grey + alpha, and the right-to-left
+    # descriptor bit (which the reference's decoder ignores)
+    def tga2(wt, ht, kind, bpp, texels, descriptor=0, cmap=None, cmap_bits=0, cmap_first=0, rle=False):
+        px = bpp // 8
+        data = b"".join(texels)
+        if rle:
+            out, i, n = bytearray(), 0, wt * ht
+            while i < n:
+                run = 1
+                while i + run < n and run < 128 and texels[i + run] == texels[i]:
+                    run += 1
+                if run > 1:
+                    out.append(128 | (run - 1)); out += texels[i]; i += run
+                else:
+                    lit = min(3, n - i)
+                    out.append(lit - 1); out += b"".join(texels[i:i + lit]); i += lit
+            data = bytes(out)
+        head = struct.pack("<BBBHHBHHHHBB", 0, 1 if cmap else 0, kind + (8 if rle else 0), cmap_first, len(cmap) if cmap else 0, cmap_bits, 0, 0, wt, ht, bpp, descriptor)
+        return head + (b"\0" * cmap_first + b"".join(cmap) if cmap else b"") + data
+    cm24 = [bytes(int(x) for x in c) for c in rng.integers(0, 256, (40, 3))]
+    idx = [bytes([int(v)]) for v in rng.integers(0, 40, w * h)]
+    idx[7] = bytes([200])  # outside the palette: entry 0
+    fx["tex_mapped8.tga"] = tga2(w, h, 1, 8, idx, cmap=cm24, cmap_bits=24)
+    cm16 = [struct.pack("<H", int(v)) for v in rng.integers(0, 1 << 16, 300)]
+    idx16 = [struct.pack("<H", int(v)) for v in rng.integers(0, 300, w * h)]
+    idx16[10:16] = [idx16[10]] * 6
+    fx["tex_mapped16_rle.tga"] = tga2(w, h, 1, 16, idx16, descriptor=0x20, cmap=cm16, cmap_bits=16, cmap_first=4, rle=True)
+    fx["tex_555.tga"] = tga2(w, h, 2, 16, [struct.pack("<H", int(v)) for v in rng.integers(0, 1 << 16, w * h)])
+    fx["tex_greyalpha16.tga"] = tga2(w, h, 3, 16, [bytes(int(x) for x in c) for c in rng.integers(0, 256, (w * h, 2))], descriptor=8)
+    fx["tex_24_right_to_left.tga"] = tga2(w, h, 2, 24, [bytes(int(x) for x in c) for c in rng.integers(0, 256, (w * h, 3))], descriptor=0x10)
+
+    # PNM with a maximum other than 255: below, the bytes are taken as they are; above, samples are two bytes
+    deep = rng.integers(0, 1001, (h, w, 3))
+    fx["tex_max1000.ppm"] = b"P6\n# seeded\n%d %d\n1000\n" % (w, h) + deep.astype(">u2").tobytes()
+    fx["tex_max65535.pgm"] = b"P5 %d %d 65535\n" % (w, h) + rng.integers(0, 65536, (h, w)).astype(">u2").tobytes()
+    fx["tex_max100.ppm"] = b"P6 %d %d 100 " % (w, h) + rng.integers(0, 101, (h, w, 3)).astype(np.uint8).tobytes()
     return fx
 
 

@@ -248,9 +248,12 @@ def test_bitmap_formats_match_the_reference(pkg, golden_dir):
     index, an image smaller than its canvas with a background index (red and blue exchanged there, as the reference's decoder
     leaves them); Radiance HDR flat and run-length coded through that decoder's tone curve; PSD 8 / 16 bit raw and PackBits RGBA
     un-matted from white; Softimage PIC raw, mixed and pure run-length packets with and without alpha, 16-bit run lengths.
-    With these every format the reference's loader accepts is read here."""
+    BMP also with 16 bits per pixel (5-5-5, 5-6-5), channel masks at odd places, 4-4-4-4 with alpha in a V4 header, 4- and 1-bit
+    palettes; TGA also colour-mapped (8- and 16-bit indices, 24-bit and 5-5-5 entries, an index outside the palette), 5-5-5 true
+    colour, grey + alpha, the ignored right-to-left bit; PNM with maxima of 100, 1000 and 65535.
+    With these every format (and every variant of it) the reference's loader accepts is read here."""
     answers = json.load(open(os.path.join(golden_dir, "bitmap_known_answers.json")))
-    assert len(answers) >= 46 and all(sum(n.endswith(e) for n in answers) >= k for e, k in ((".jpg", 14), (".gif", 6), (".hdr", 3), (".psd", 3), (".pic", 3)))
+    assert len(answers) >= 60 and all(sum(n.endswith(e) for n in answers) >= k for e, k in ((".jpg", 14), (".gif", 6), (".hdr", 3), (".psd", 3), (".pic", 3), (".bmp", 10), (".tga", 8)))
     f32 = np.float32
     for name, rows in sorted(answers.items()):
         s = pkg.Scene()
