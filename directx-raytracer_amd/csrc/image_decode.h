@@ -6,7 +6,7 @@
 // PPM / PGM -- and yield what stbi_load yields for them, that decoder's oddities included where a texel depends on them: rows top
 // to bottom, `channels` bytes per texel in the file's own channel count (1 grey, 2 grey + alpha, 3 RGB, 4 RGBA; 16-bit PNG / PSD
 // samples reduced to their high byte).  Known answers: tests/golden/bitmap_known_answers.json, produced by the reference's own
-// CRTTextureBitmap over the same 61 files (oracle/make_golden.py).
+// CRTTextureBitmap over the same 73 files (oracle/make_golden.py).
 #pragma once
 
 #include <string>

@@ -139,14 +139,20 @@ def _png(w, h, depth, color, rows, level=9, strategy=None, interlace=False, pale
     if not interlace:
         raw = filtered(rows)
     else:
-        assert depth >= 8
         x0, y0, dx, dy = [0, 4, 0, 2, 0, 1, 0], [0, 0, 4, 0, 2, 0, 1], [8, 8, 4, 4, 2, 2, 1], [8, 8, 8, 4, 4, 2, 2]
         px = ch * depth // 8
         raw = b""
         for p in range(7):
             lines = []
             for y in range(y0[p], h, dy[p]):
-                line = b"".join(rows[y][x * px:(x + 1) * px] for x in range(x0[p], w, dx[p]))
+                if depth >= 8:
+                    line = b"".join(rows[y][x * px:(x + 1) * px] for x in range(x0[p], w, dx[p]))
+                else:  # one channel of 1 / 2 / 4 bits: unpack the row's samples, take the pass's columns, pack them again
+                    vals = [(rows[y][(x * depth) >> 3] >> (8 - depth - ((x * depth) & 7))) & ((1 << depth) - 1) for x in range(x0[p], w, dx[p])]
+                    acc = bytearray((len(vals) * depth + 7) // 8)
+                    for i, v in enumerate(vals):
+                        acc[(i * depth) >> 3] |= v << (8 - depth - ((i * depth) & 7))
+                    line = bytes(acc)
                 if line:
                     lines.append(line)
             if lines:
@@ -169,7 +175,8 @@ def _png(w, h, depth, color, rows, level=9, strategy=None, interlace=False, pale
 
 
 ONE_CHANNEL = {"tex_grey8_stored.png": (9, 6), "tex_grey1.png": (13, 6), "tex_grey8.tga": (9, 6), "tex_grey.jpg": (21, 19),
-               "tex_proggrey.jpg": (20, 21), "tex_max65535.pgm": (9, 6)}  # name -> (width, height)
+               "tex_proggrey.jpg": (20, 21), "tex_max65535.pgm": (9, 6), "tex_grey2.png": (13, 6), "tex_grey4.png": (13, 6), "tex_grey16.png": (9, 6),
+               "tex_grey4_adam7.png": (23, 19)}  # name -> (width, height)
 
 
 def bitmap_fixtures():
@@ -516,6 +523,33 @@ def bitmap_fixtures():
     fx["tex_max1000.ppm"] = b"P6\n# seeded\n%d %d\n1000\n" % (w, h) + deep.astype(">u2").tobytes()
     fx["tex_max65535.pgm"] = b"P5 %d %d 65535\n" % (w, h) + rng.integers(0, 65536, (h, w)).astype(">u2").tobytes()
     fx["tex_max100.ppm"] = b"P6 %d %d 100 " % (w, h) + rng.integers(0, 101, (h, w, 3)).astype(np.uint8).tobytes()
+
+    # PNG, the remaining depth x colour-type combinations, colour-key transparency, and Adam7 below 8 bits
+    def packed(vals, depth):
+        out = []
+        for row in vals:
+            acc = bytearray((len(row) * depth + 7) // 8)
+            for i, v in enumerate(row):
+                acc[(i * depth) >> 3] |= int(v) << (8 - depth - ((i * depth) & 7))
+            out.append(bytes(acc))
+        return out
+    fx["tex_grey2.png"] = _png(13, h, 2, 0, packed(rng.integers(0, 4, (h, 13)), 2))
+    fx["tex_grey4.png"] = _png(13, h, 4, 0, packed(rng.integers(0, 16, (h, 13)), 4))
+    g16 = rng.integers(0, 65536, (h, w))
+    fx["tex_grey16.png"] = _png(w, h, 16, 0, [g16[y].astype(">u2").tobytes() for y in range(h)])
+    fx["tex_greyalpha16.png"] = _png(w, h, 16, 4, [rng.integers(0, 65536, (w, 2))[:, :].astype(">u2").tobytes() for _ in range(h)])
+    fx["tex_rgba16.png"] = _png(w, h, 16, 6, [rng.integers(0, 65536, (w, 4)).astype(">u2").tobytes() for _ in range(h)])
+    pal256 = rng.integers(0, 256, 256 * 3).tolist()
+    fx["tex_pal8.png"] = _png(w, h, 8, 3, [rng.integers(0, 256, w, dtype=np.uint8).tobytes() for _ in range(h)], palette=pal256)
+    fx["tex_pal1.png"] = _png(13, h, 1, 3, packed(rng.integers(0, 2, (h, 13)), 1), palette=pal256[:6])
+    fx["tex_pal2_adam7.png"] = _png(23, 19, 2, 3, packed(rng.integers(0, 4, (19, 23)), 2), palette=pal256[:12], interlace=True, trns=[255, 0, 90])
+    fx["tex_grey4_adam7.png"] = _png(23, 19, 4, 0, packed(rng.integers(0, 16, (19, 23)), 4), interlace=True)
+    key = rng.integers(0, 4, (h, w, 3)) * 85  # few distinct colours: the colour key below names one that occurs
+    fx["tex_rgb8_key.png"] = _png(w, h, 8, 2, [key[y].astype(np.uint8).tobytes() for y in range(h)], trns=[0, 85, 0, 170, 0, 0])
+    gk = rng.integers(0, 4, (h, w)) * 85
+    fx["tex_grey8_key.png"] = _png(w, h, 8, 0, [gk[y].astype(np.uint8).tobytes() for y in range(h)], trns=[0, 170])
+    g16k = rng.integers(0, 3, (h, w)) * 30000
+    fx["tex_grey16_key.png"] = _png(w, h, 16, 0, [g16k[y].astype(">u2").tobytes() for y in range(h)], trns=[0x75, 0x30])
     return fx
 
 

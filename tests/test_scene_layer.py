@@ -240,7 +240,8 @@ def test_bitmap_formats_match_the_reference(pkg, golden_dir):
     (R/CRTTextureBitmap.cpp:10); this repo with its own decoders (csrc/image_decode.cpp: PNG with its own inflate, BMP, TGA;
     csrc/jpeg_decode.cpp).  Known answers: the reference's CRTTextureBitmap::getColor over the same seeded files
     (oracle/make_golden.py), bit for bit -- PNG in every colour type (grey, grey + alpha, RGB, RGBA, palette with and without
-    tRNS), 1 / 4 / 8 / 16 bits, all five scanline filters, stored / fixed / dynamic deflate blocks, several IDAT chunks, Adam7;
+    tRNS; colour-key tRNS on grey and RGB files, which adds an alpha channel) at every bit depth each allows (1 / 2 / 4 / 8 / 16,
+    Adam7 also below 8 bits), all five scanline filters, stored / fixed / dynamic deflate blocks, several IDAT chunks, Adam7;
     BMP 24 / 32 bit / palette / top-down; TGA raw and run-length coded, colour and grey; JPEG baseline and progressive (also
     with optimised Huffman tables), 4:4:4 / 4:2:2 / 4:2:0 / 4:1:1, grey, Adobe CMYK, restart intervals, quality 10, and images one
     or two texels wide -- a JPEG's texels depend on the decoder's inverse DCT, chroma filter and colour matrix, so these pin the
@@ -253,7 +254,7 @@ def test_bitmap_formats_match_the_reference(pkg, golden_dir):
     colour, grey + alpha, the ignored right-to-left bit; PNM with maxima of 100, 1000 and 65535.
     With these every format (and every variant of it) the reference's loader accepts is read here."""
     answers = json.load(open(os.path.join(golden_dir, "bitmap_known_answers.json")))
-    assert len(answers) >= 60 and all(sum(n.endswith(e) for n in answers) >= k for e, k in ((".jpg", 14), (".gif", 6), (".hdr", 3), (".psd", 3), (".pic", 3), (".bmp", 10), (".tga", 8)))
+    assert len(answers) >= 72 and all(sum(n.endswith(e) for n in answers) >= k for e, k in ((".jpg", 14), (".gif", 6), (".hdr", 3), (".psd", 3), (".pic", 3), (".bmp", 10), (".tga", 8), (".png", 22)))
     f32 = np.float32
     for name, rows in sorted(answers.items()):
         s = pkg.Scene()
