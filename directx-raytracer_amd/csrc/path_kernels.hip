@@ -406,7 +406,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
     unsigned long long pT[3] = { 0, 0, 0 }, pTN[3] = { 0, 0, 0 }, pTL[3] = { 0, 0, 0 };
     uint32_t pIN[3] = { 0, 0, 0 }, pIL[3] = { 0, 0, 0 }, pLN[3] = { 0, 0, 0 }, pLL[3] = { 0, 0, 0 };
     unsigned long long pT0 = 0;
-    const unsigned long long pK0 = __builtin_amdgcn_s_memtime();
+    const unsigned long long pK0 = __builtin_amdgcn_s_memtime(), pR0 = __builtin_amdgcn_s_memrealtime();
 #define CRT_PATH_PROF_BEGIN() { stack.tNode = stack.tLeaf = 0; stack.itNode = stack.itLeaf = stack.lanesNode = stack.lanesLeaf = 0; pT0 = __builtin_amdgcn_s_memtime(); }
 #define CRT_PATH_PROF_END(S) { pT[S] += __builtin_amdgcn_s_memtime() - pT0; pTN[S] += stack.tNode; pTL[S] += stack.tLeaf; pIN[S] += stack.itNode; pIL[S] += stack.itLeaf; pLN[S] += stack.lanesNode; pLL[S] += stack.lanesLeaf; }
 #else
@@ -555,6 +555,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(CRT_PATH_WAV
 #if CRT_PROF
     if (COUNT && lane == 0) { // counters[4] = wave lifetime, then 7 words per stage: cycles, in node steps, in leaf steps, node / leaf phases, lanes in them
         atomicAdd(&p.counters[4], __builtin_amdgcn_s_memtime() - pK0);
+        atomicAdd(&p.counters[26], __builtin_amdgcn_s_memrealtime() - pR0); // the same on the constant 100 MHz clock: sum of the wavefronts' lives
+        atomicAdd(&p.counters[27], 1ull);
         for (int st = 0; st < 3; st++) {
             unsigned long long* c = p.counters + 5 + 7 * st;
             atomicAdd(&c[0], pT[st]); atomicAdd(&c[1], pTN[st]); atomicAdd(&c[2], pTL[st]);

@@ -22,13 +22,17 @@ def main():
             frame = torch.zeros(W * H, dtype=torch.int32, device="cuda")
         for o in [x for x in sys.argv[1:] if "=" in x]: r.set_option(o.split("=")[0], int(o.split("=")[1]))
         r.change_shading_mode(pkg.MODE_PATH); r.set_path_params(4, 3, 1234)
-        for _ in range(2): r.render_frame_device(W, H, frame.data_ptr(), stats=True)
+        r.set_counting(True)  # (the instrumented variant measures the costs the launch order is sorted by, too)
+        for _ in range(12): r.render_frame_device(W, H, frame.data_ptr(), stats=True)  # the launch order settles
         r.set_counting(True)
         st = r.render_frame_device(W, H, frame.data_ptr(), stats=True)
         c = r.read_counters().astype(np.float64)
         r.set_counting(False)
         print("mode 200 %dx%d: kernel %.3f ms (instrumented); rays closest %d shadow %d" % (W, H, st["kernel_ms"], c[3], c[2]))
         life = c[4]
+        if c[27] > 0:  # how full the launch keeps its wavefront slots: sum of the wavefronts' lives / (wavefronts x launch duration)
+            print("  %d persistent wavefronts alive %.1f%% of the launch on average (100 MHz clock: %.3f ms of %.3f ms)" % (
+                c[27], 100.0 * c[26] / c[27] / (st["kernel_ms"] * 1e5), c[26] / c[27] / 1e5, st["kernel_ms"]))
         for i, name in enumerate(("A camera rays", "B shade + shadow rays" , "C bounce rays")):
             t, tn, tl, itn, itl, lan, lal = c[5 + 7 * i: 12 + 7 * i]
             if t == 0: continue
