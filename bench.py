@@ -238,7 +238,10 @@ def main():
                     "the CPU baseline is switched off")
     ap.add_argument("--spinup-ms", type=float, default=150.0, help="untimed frames before the timed region, by wall time: clocks and "
                     "caches at their steady state even for a short --steps")
-    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: only with --rendezvous-only (CPU tests)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"], help="gloo: with --rendezvous-only (CPU tests), or with "
+                    "--same-device: the N > 1 code path with every rank on GPU 0 and the tiles exchanged through host memory (RCCL "
+                    "refuses two ranks on one GPU) -- a rehearsal of the rank logic on a one-GPU box, never a measurement")
+    ap.add_argument("--same-device", action="store_true", help="every rank renders on GPU 0 (rehearsal with --backend gloo)")
     ap.add_argument("--rendezvous-only", action="store_true", help="the ranks meet, add up their ranks and leave: checks the launch path "
                     "without a GPU (tests/test_tiling.py)")
     args = ap.parse_args()
@@ -274,14 +277,22 @@ def main():
         return
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product has no CPU path")
+    if args.same_device:
+        if args.backend != "gloo":
+            raise SystemExit("bench.py: --same-device needs --backend gloo (RCCL refuses two ranks on one GPU)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     multi = world > 1 or args.force_dist
+    ctl = "cuda" if args.backend == "nccl" else "cpu"  # where the small control tensors of the collectives live
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))  # nccl == RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     pkg = entry.load_package()
     scenes = importlib.import_module(entry.PKG_NAME + ".scenes")
@@ -405,7 +416,7 @@ def main():
             # every rank issues the same number of steps (they contain collectives): rank 0's clock decides, chunk by chunk
             go = (time.perf_counter() - t_spin) * 1e3 < args.spinup_ms
             if multi:
-                flag = torch.tensor([1 if go else 0], dtype=torch.int32, device="cuda")
+                flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=ctl)
                 dist.broadcast(flag, src=0)
                 go = bool(flag.item())
             if not go:
@@ -431,7 +442,7 @@ def main():
         stream_ms = ev0.elapsed_time(ev1)  # HIP events over the timed region (the main stream joins the other streams first)
         r.set_stream(main_stream.cuda_stream)
         if multi:
-            tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=ctl)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             elapsed = float(tmax.item())
         return elapsed, stream_ms, warmup + extra
@@ -541,6 +552,8 @@ def main():
             "stream_ms_per_step": stream_ms / args.steps,
         }
         line.update(extras)
+        if args.same_device:
+            line["rehearsal"] = "every rank on GPU 0, tiles exchanged through host memory over gloo: exercises the rank logic, measures nothing"
         if not multi:
             # dominant (only) kernel.  Its average launch duration = HIP events on its stream around the K back-to-back launches
             # of the timed region / K (with 1 launch in flight the stream holds nothing else: the 1-workgroup sortUnitsKernel

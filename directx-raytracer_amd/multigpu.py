@@ -39,6 +39,11 @@ def gather_batch(staging, w, h, n_frames, untile, gathered=None):
         gathered = torch.empty(n * staging.numel(), dtype=staging.dtype, device=staging.device)
     if not dist.is_initialized():
         gathered.copy_(staging)
+    elif dist.get_backend() == "gloo" and staging.is_cuda:
+        # rehearsal on one GPU (bench.py --backend gloo --same-device): the tiles travel through host memory
+        host = torch.empty(n * staging.numel(), dtype=staging.dtype)
+        dist.all_gather_into_tensor(host, staging.cpu())
+        gathered.copy_(host)
     else:
         dist.all_gather_into_tensor(gathered, staging)
     return [untile(gathered, f) for f in range(n_frames)]

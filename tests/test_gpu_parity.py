@@ -246,6 +246,27 @@ def test_rccl_gather_path_of_bench_in_a_fresh_process():
     assert "all-gather" in line["config"]["parallelism"] or line["n_gpus"] == 1
 
 
+def test_bench_three_ranks_rehearsed_on_one_gpu():
+    """`python bench.py --gpus 3` with no launcher environment: bench.py starts three rank processes itself; with --backend gloo
+    --same-device they all render on GPU 0 and exchange their tiles through host memory (RCCL refuses several ranks on one GPU).
+    Everything of the N > 1 path except the collective's transport runs as it will on three GPUs: the rank-dependent tile shares
+    with split packets, four launches in flight on four streams, the spin-up whose length rank 0 broadcasts, the per-rank
+    barriers, the one-launch-in-flight leg, and rank 0's comparison of the gathered frame with the oracle's."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--backend", "gloo", "--same-device", "--steps", "8",
+                          "--warmup", "2", "--spinup-ms", "30", "--no-cpu-baseline", "--check-dist-frame"],
+                         capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
+    line = json.loads([l for l in out.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 3 and line["frame_matches_oracle"] is True and line["frame_rows_checked"] == 1080
+    assert line["config"]["launches_in_flight"] == 4 and line["one_launch_in_flight"]["value"] > 0
+    assert line["message_bytes_per_rank"] == 2720 * 1024 and "rehearsal" in line
+
+
 def test_bench_c5_config_runs_and_matches_the_oracle_on_sampled_rows():
     """`bench.py --config c5` (BASELINE.json configs[4]: 5M triangles, 3840x2160, 4 spp, 3 bounces) through the N>1 path with
     the one rank a box has: the tile-partitioned path-traced frame equals the oracle's on the rows the CPU sample covers."""
