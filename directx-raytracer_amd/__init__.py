@@ -39,7 +39,7 @@ ABI_SYMBOLS = [
     "crt_set_shading_mode", "crt_set_miss_color", "crt_set_counting", "crt_set_option", "crt_debug_read_timeline", "crt_debug_read_counters", "crt_render_frame", "crt_render_frame_device",
     "crt_tile_count", "crt_tile_slots", "crt_render_tiles_device", "crt_render_frames_batch_device", "crt_render_tiles_batch_device",
     "crt_untile_device", "crt_untile_batch_device", "crt_set_stream", "crt_reset_stream",
-    "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_host_alloc", "crt_host_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_export4q", "crt_bvh_quantize4", "crt_comm_unique_id", "crt_comm_init", "crt_comm_destroy", "crt_comm_info", "crt_render_frame_distributed", "crt_bvh_build_host4", "crt_build_stats",
+    "crt_synchronize", "crt_bvh_info", "crt_bvh_export", "crt_bvh_build_host", "crt_free", "crt_host_alloc", "crt_host_free", "crt_bvh_info4", "crt_bvh_export4", "crt_bvh_export4q", "crt_bvh_quantize4", "crt_comm_unique_id", "crt_comm_init", "crt_comm_init_host", "crt_comm_destroy", "crt_comm_info", "crt_render_frame_distributed", "crt_bvh_build_host4", "crt_build_stats",
     "crt_scene_load", "crt_scene_save", "crt_scene_new", "crt_scene_free", "crt_scene_add_mesh", "crt_scene_add_light",
     "crt_scene_add_material", "crt_scene_mesh_count", "crt_scene_mesh", "crt_scene_light_count", "crt_scene_light",
     "crt_scene_material_count", "crt_scene_material", "crt_scene_texture_count", "crt_scene_texture_color", "crt_scene_add_texture",
@@ -157,6 +157,7 @@ def lib():
         "crt_bvh_export4q": (C.c_int, [vp, vp]),
         "crt_comm_unique_id": (C.c_int, [vp]),
         "crt_comm_init": (C.c_int, [vp, u32, u32, vp]),
+        "crt_comm_init_host": (C.c_int, [vp, u32, u32, C.c_char_p]),
         "crt_comm_destroy": (C.c_int, [vp]),
         "crt_comm_info": (C.c_int, [vp, C.POINTER(u32), C.POINTER(u32)]),
         "crt_render_frame_distributed": (C.c_int, [vp, u32, u32, vp, vp, C.POINTER(FrameStats)]),

@@ -13,15 +13,23 @@
 #include <rccl/rccl.h> // types and prototypes only: the library is dlopen'ed by crt_comm_init (no link-time dependency)
 
 #include <dlfcn.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <cerrno>
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 using crt::RenderParams;
@@ -150,6 +158,7 @@ struct crt_ctx {
 
     // native multi-GPU frame assembly (crt_comm_init): RCCL communicator + per-ring-slot staging / gathered / frame buffers
     ncclComm_t comm = nullptr;
+    struct HostExchange* hostComm = nullptr; // crt_comm_init_host: the tiles travel through shared host memory instead of RCCL
     uint32_t commRank = 0, commRanks = 0;
     void* dStage[kRing] = {};
     void* dGather[kRing] = {};
@@ -1275,9 +1284,124 @@ int crt_comm_init(crt_ctx* c, uint32_t rank, uint32_t n_ranks, const void* uniqu
     return CRT_OK;
 }
 
+// ---- the same frame assembly with shared host memory as the transport: for ranks that share ONE GPU (RCCL refuses that), i.e. for
+// rehearsing the multi-rank path on a one-GPU machine, and as a fallback where RCCL cannot be loaded.  A POSIX shared-memory object
+// holds a header (arrival counter + generation of a sense-reversing barrier) and the ranks' tile slices; per frame: copy the own
+// slice in, barrier, copy all slices out, barrier.  Never a measurement of anything.
+struct HostExchange {
+    struct Header {
+        std::atomic<uint32_t> magic, arrive, generation;
+        uint32_t nRanks;
+        uint64_t capacity;
+    };
+    static constexpr uint32_t kMagic = 0x43525431u;
+    static constexpr size_t kDataAt = 4096;
+    int fd = -1;
+    void* map = nullptr;
+    size_t bytes = 0;
+    std::string name;
+    bool owner = false;
+    Header* header() const { return static_cast<Header*>(map); }
+    unsigned char* data() const { return static_cast<unsigned char*>(map) + kDataAt; }
+    bool barrier(uint32_t n) const // false: a peer did not arrive within a minute
+    {
+        Header* h = header();
+        const uint32_t gen = h->generation.load(std::memory_order_acquire);
+        if (h->arrive.fetch_add(1, std::memory_order_acq_rel) + 1 == n) {
+            h->arrive.store(0, std::memory_order_relaxed);
+            h->generation.fetch_add(1, std::memory_order_acq_rel);
+            return true;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        while (h->generation.load(std::memory_order_acquire) == gen) {
+            if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(60)) return false;
+            std::this_thread::sleep_for(std::chrono::microseconds(50));
+        }
+        return true;
+    }
+    void close()
+    {
+        if (map) munmap(map, bytes);
+        if (fd >= 0) ::close(fd);
+        if (owner && !name.empty()) shm_unlink(name.c_str());
+        map = nullptr;
+        fd = -1;
+    }
+};
+
+int crt_comm_init_host(crt_ctx* c, uint32_t rank, uint32_t n_ranks, const char* name)
+{
+    if (!c) return CRT_EINVAL;
+    if (!name || name[0] != '/' || n_ranks == 0 || rank >= n_ranks) return fail(c, CRT_EINVAL, "crt_comm_init_host: bad arguments (rank %u of %u, name must start with '/')", rank, n_ranks);
+    if (c->comm || c->hostComm) return fail(c, CRT_ESTATE, "crt_comm_init_host: the context already has a communicator (crt_comm_destroy first)");
+    std::unique_ptr<HostExchange> x(new HostExchange);
+    x->name = name;
+    x->bytes = HostExchange::kDataAt + (size_t(1) << 28); // room for a 8K RGBA8 frame; pages are only taken when touched
+    if (rank == 0) {
+        x->fd = shm_open(name, O_CREAT | O_EXCL | O_RDWR, 0600);
+        if (x->fd < 0) return fail(c, CRT_EIO, "crt_comm_init_host: cannot create shared memory '%s': %s", name, std::strerror(errno));
+        x->owner = true;
+        if (ftruncate(x->fd, static_cast<off_t>(x->bytes)) != 0) {
+            const int e = errno;
+            x->close();
+            return fail(c, CRT_EIO, "crt_comm_init_host: cannot size '%s': %s", name, std::strerror(e));
+        }
+    } else {
+        for (int tries = 0; tries < 6000 && x->fd < 0; tries++) { // up to 60 s for rank 0 to come up
+            x->fd = shm_open(name, O_RDWR, 0600);
+            if (x->fd < 0) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+        if (x->fd < 0) return fail(c, CRT_EIO, "crt_comm_init_host: rank %u found no shared memory '%s'", rank, name);
+        struct stat st;
+        for (int tries = 0; tries < 6000; tries++) { // ... and to size it
+            if (fstat(x->fd, &st) == 0 && static_cast<size_t>(st.st_size) >= x->bytes) break;
+            std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+    }
+    x->map = mmap(nullptr, x->bytes, PROT_READ | PROT_WRITE, MAP_SHARED, x->fd, 0);
+    if (x->map == MAP_FAILED) {
+        const int e = errno;
+        x->map = nullptr;
+        x->close();
+        return fail(c, CRT_EIO, "crt_comm_init_host: cannot map '%s': %s", name, std::strerror(e));
+    }
+    HostExchange::Header* h = x->header();
+    if (rank == 0) {
+        h->arrive.store(0);
+        h->generation.store(0);
+        h->nRanks = n_ranks;
+        h->capacity = x->bytes - HostExchange::kDataAt;
+        h->magic.store(HostExchange::kMagic, std::memory_order_release);
+    } else {
+        int tries = 0;
+        while (h->magic.load(std::memory_order_acquire) != HostExchange::kMagic && tries++ < 6000) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        if (h->magic.load(std::memory_order_acquire) != HostExchange::kMagic || h->nRanks != n_ranks) {
+            x->close();
+            return fail(c, CRT_EIO, "crt_comm_init_host: '%s' is not this launch's exchange (%u ranks expected)", name, n_ranks);
+        }
+    }
+    if (!x->barrier(n_ranks)) { // collective, like crt_comm_init: everybody is attached before anybody goes on (and before rank 0 may unlink)
+        x->close();
+        return fail(c, CRT_EIO, "crt_comm_init_host: not all %u ranks arrived within a minute", n_ranks);
+    }
+    c->hostComm = x.release();
+    c->commRank = rank;
+    c->commRanks = n_ranks;
+    return CRT_OK;
+}
+
 int crt_comm_destroy(crt_ctx* c)
 {
     if (!c) return CRT_EINVAL;
+    if (c->hostComm) {
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        c->hostComm->close();
+        delete c->hostComm;
+        c->hostComm = nullptr;
+        c->commRanks = 0;
+        return CRT_OK;
+    }
     if (!c->comm) return CRT_OK;
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
@@ -1299,7 +1423,7 @@ int crt_render_frame_distributed(crt_ctx* c, uint32_t w, uint32_t h, void* d_rgb
 {
     int rc = checkRenderable(c, w, h);
     if (rc) return rc;
-    if (!c->comm) return fail(c, CRT_ESTATE, "crt_render_frame_distributed: no communicator (crt_comm_init first)");
+    if (!c->comm && !c->hostComm) return fail(c, CRT_ESTATE, "crt_render_frame_distributed: no communicator (crt_comm_init first)");
     const auto t0 = std::chrono::steady_clock::now();
     HIP_TRY(c, hipSetDevice(c->device));
     const uint32_t n = c->commRanks, slots = crt_tile_slots(w, h, n);
@@ -1317,8 +1441,19 @@ int crt_render_frame_distributed(crt_ctx* c, uint32_t w, uint32_t h, void* d_rgb
     crt_frame_stats local;
     rc = crt_render_tiles_device(c, w, h, c->commRank, n, c->dStage[k], stats ? &local : nullptr);
     if (rc) return rc;
-    const ncclResult_t r = rccl().allGather(c->dStage[k], c->dGather[k], per, ncclUint8, c->comm, c->stream);
-    if (r != ncclSuccess) return fail(c, CRT_EHIP, "ncclAllGather failed: %s", rccl().getErrorString(r));
+    if (c->comm) {
+        const ncclResult_t r = rccl().allGather(c->dStage[k], c->dGather[k], per, ncclUint8, c->comm, c->stream);
+        if (r != ncclSuccess) return fail(c, CRT_EHIP, "ncclAllGather failed: %s", rccl().getErrorString(r));
+    } else { // through shared host memory: own slice in, everybody waits, all slices out, everybody waits again before the next frame's writes
+        HostExchange* x = c->hostComm;
+        if (per * n > x->header()->capacity) return fail(c, CRT_EINVAL, "crt_render_frame_distributed: frame too large for the host exchange");
+        HIP_TRY(c, hipMemcpyAsync(x->data() + per * c->commRank, c->dStage[k], per, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!x->barrier(n)) return fail(c, CRT_EIO, "crt_render_frame_distributed: a rank did not deliver its tiles within a minute");
+        HIP_TRY(c, hipMemcpyAsync(c->dGather[k], x->data(), per * n, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!x->barrier(n)) return fail(c, CRT_EIO, "crt_render_frame_distributed: a rank did not collect the tiles within a minute");
+    }
     rc = crt_untile_device(c, w, h, n, c->dGather[k], frame);
     if (rc) return rc;
     if (host_rgba8) HIP_TRY(c, hipMemcpyAsync(host_rgba8, frame, static_cast<size_t>(w) * h * 4, hipMemcpyDeviceToHost, c->stream));

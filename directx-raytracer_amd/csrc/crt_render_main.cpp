@@ -11,6 +11,7 @@
 #include "renderer.h"
 
 #include <signal.h>
+#include <sys/mman.h>
 #include <sys/wait.h>
 #include <time.h>
 #include <unistd.h>
@@ -37,7 +38,9 @@ static void usage()
                  "   [--spp N] [--bounces N] [--seed N]   mode 200 (path tracing)\n"
                  "   [--phong KS_PERMILLE:EXPONENT]       mode 100 specular term\n"
                  "   [--out prefix] [--png] [--count]      frames as prefix_N.ppm, or prefix_N.png with --png\n"
-                 "   [--ranks N [--device-base D] [--id-file PATH]]   N processes / GPUs, RCCL gather per frame\n");
+                 "   [--ranks N [--device-base D] [--id-file PATH]]   N processes / GPUs, RCCL gather per frame\n"
+                 "   [--host-exchange [--same-device]]   with --ranks: tiles through shared host memory instead of RCCL; --same-device puts every\n"
+                 "                                       rank on --device (a rehearsal of the multi-rank path on one GPU)\n");
 }
 
 namespace {
@@ -47,7 +50,7 @@ struct Args {
     int frames = 1, device = 0, deviceBase = 0, ranks = 0, rank = -1;
     int spp = -1, bounces = -1, seed = -1, phongKs = -1, phongExp = -1;
     float orbit = 0.f, pitch = 0.f, forward = 0.f, right = 0.f, zoom = 0.f;
-    bool count = false, png = false;
+    bool count = false, png = false, hostExchange = false, sameDevice = false;
     unsigned long long nonce = 0; // names the launch in the id file (set by the --ranks parent)
     std::map<int, uint32_t> modeAt;
 };
@@ -78,7 +81,7 @@ void applyScriptLine(const std::string& line, crt::Renderer& renderer)
 int runRank(const Args& a)
 {
     crt::Renderer renderer;
-    const int device = a.ranks > 0 ? a.deviceBase + a.rank : a.device;
+    const int device = (a.ranks > 0 && !a.sameDevice) ? a.deviceBase + a.rank : a.device;
     renderer.prepareForRendering(a.scene, device);
     renderer.setFrameSize(a.w, a.h);
     renderer.changeShadingMode(a.mode);
@@ -88,7 +91,8 @@ int runRank(const Args& a)
     if (a.seed >= 0) renderer.setOption("seed", a.seed);
     if (a.phongKs >= 0) renderer.setOption("phong_ks", a.phongKs);
     if (a.phongExp >= 0) renderer.setOption("phong_exponent", a.phongExp);
-    if (a.ranks > 0) renderer.joinRanks(static_cast<uint32_t>(a.rank), static_cast<uint32_t>(a.ranks), a.idFile, a.nonce);
+    if (a.ranks > 0 && a.hostExchange) renderer.joinRanksThroughHostMemory(static_cast<uint32_t>(a.rank), static_cast<uint32_t>(a.ranks), a.nonce);
+    else if (a.ranks > 0) renderer.joinRanks(static_cast<uint32_t>(a.rank), static_cast<uint32_t>(a.ranks), a.idFile, a.nonce);
     const bool talk = a.ranks <= 0 || a.rank == 0;
     std::vector<std::string> script;
     if (!a.pathFile.empty()) {
@@ -203,6 +207,11 @@ int launchRanks(const Args& a, int argc, char** argv)
             if (k > 0) kill(k, SIGKILL);
     }
     std::remove(idFile.c_str());
+    if (a.hostExchange) { // normally gone already (rank 0 removes it); a rank that was stopped may have left it behind
+        char name[64];
+        std::snprintf(name, sizeof(name), "/crt_render_%016llx", nonce);
+        shm_unlink(name);
+    }
     return rc;
 }
 } // namespace
@@ -241,6 +250,8 @@ int main(int argc, char** argv)
         else if (s == "--out") a.out = next("--out");
         else if (s == "--count") a.count = true;
         else if (s == "--png") a.png = true;
+        else if (s == "--host-exchange") a.hostExchange = true;
+        else if (s == "--same-device") a.sameDevice = true;
         else if (s == "--ranks") a.ranks = std::atoi(next("--ranks"));
         else if (s == "--rank") a.rank = std::atoi(next("--rank"));
         else if (s == "--device-base") a.deviceBase = std::atoi(next("--device-base"));

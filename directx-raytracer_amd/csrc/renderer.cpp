@@ -136,6 +136,16 @@ void Renderer::joinRanks(uint32_t rankIn, uint32_t nRanksIn, const std::string& 
     nRanks = nRanksIn;
 }
 
+void Renderer::joinRanksThroughHostMemory(uint32_t rankIn, uint32_t nRanksIn, unsigned long long nonce)
+{
+    if (!ctx) throw std::runtime_error("joinRanksThroughHostMemory before prepareForRendering");
+    char name[64];
+    std::snprintf(name, sizeof(name), "/crt_render_%016llx", nonce); // the launch's nonce names the shared-memory object
+    check(crt_comm_init_host(ctx, rankIn, nRanksIn, name), "crt_comm_init_host");
+    rank = rankIn;
+    nRanks = nRanksIn;
+}
+
 void Renderer::stopRendering()
 {
     if (ctx) check(crt_synchronize(ctx), "crt_synchronize");

@@ -49,6 +49,8 @@ public:
     // 128-byte id and publishes it as `idFile` (written under a temporary name, then renamed); the other ranks wait for the
     // file.  Afterwards renderFrame() renders this rank's tiles, gathers and de-interleaves: every rank holds the frame.
     void joinRanks(uint32_t rank, uint32_t nRanks, const std::string& idFile, unsigned long long nonce = 0);
+    // the same with shared host memory as the transport (crt_comm_init_host): ranks that share one GPU -- a rehearsal, not a measurement
+    void joinRanksThroughHostMemory(uint32_t rank, uint32_t nRanks, unsigned long long nonce);
     uint32_t getRank() const { return rank; }
     uint32_t getRankCount() const { return nRanks; }
 

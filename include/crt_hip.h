@@ -204,6 +204,11 @@ int crt_untile_batch_device(crt_ctx* ctx, uint32_t width, uint32_t height, uint3
 #define CRT_COMM_ID_BYTES 128
 int crt_comm_unique_id(void* id_out /* CRT_COMM_ID_BYTES */);
 int crt_comm_init(crt_ctx* ctx, uint32_t rank, uint32_t n_ranks, const void* unique_id);
+/* The same frame assembly with shared host memory as the transport, for ranks that share ONE GPU (RCCL refuses that: rehearsing the
+ * multi-rank path on a one-GPU machine) or where RCCL cannot be loaded: `name` ("/something") names a POSIX shared-memory object
+ * that rank 0 creates and removes; collective like crt_comm_init.  Per frame every rank copies its tiles into the object, waits for
+ * the others, and copies all tiles out.  Correct, slow, never a measurement. */
+int crt_comm_init_host(crt_ctx* ctx, uint32_t rank, uint32_t n_ranks, const char* name);
 int crt_comm_destroy(crt_ctx* ctx);
 int crt_comm_info(const crt_ctx* ctx, uint32_t* rank, uint32_t* n_ranks); /* n_ranks = 0: no communicator */
 int crt_render_frame_distributed(crt_ctx* ctx, uint32_t width, uint32_t height, void* d_rgba8, uint8_t* host_rgba8, crt_frame_stats* stats);

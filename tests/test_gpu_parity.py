@@ -771,8 +771,8 @@ def test_headless_driver_full_camera_controls_and_mode_switch(pkg, oracle, scene
 def test_native_rccl_gather_behind_the_c_abi(pkg, oracle, scenes, dragon, renderer, tmp_path, golden_dir):
     """crt_comm_init + crt_render_frame_distributed (csrc/crt_api.cpp): tiles -> ncclAllGather on the context's stream ->
     untile, no torch involved.  With the one rank this box has: the distributed frame equals crt_render_frame_device's and the
-    oracle's; and crt_render --ranks 1 (the C++-only launcher: parent forks the rank processes before touching the GPU) writes
-    the same images as the single-process run."""
+    oracle's; crt_render --ranks 1 (the C++-only launcher: parent forks the rank processes before touching the GPU) writes
+    the same images as the single-process run; and so do three rank processes sharing this GPU through the host-memory exchange."""
     import subprocess
     import torch
     sc = _with_normals(scenes, dragon)
@@ -815,6 +815,18 @@ def test_native_rccl_gather_behind_the_c_abi(pkg, oracle, scenes, dragon, render
     assert "rank 0's tile share of 1 ranks" in b.stdout
     for f in range(2):
         np.testing.assert_array_equal(_read_ppm(str(tmp_path / ("one_%d.ppm" % f)), 480, 270), _read_ppm(str(tmp_path / ("ranks_%d.ppm" % f)), 480, 270))
+    # THREE native rank processes on this one GPU: the launcher, the per-rank tile shares (split packets at their multi-rank
+    # default), the frame assembly and rank 0's output run as they will on three GPUs, with shared host memory carrying the tiles
+    # (crt_comm_init_host: RCCL refuses several ranks on one GPU) -- ragged size, a camera that moves, a mode switch
+    c = subprocess.run([exe, scene_file, "--mode", "100", "--size", "333x217", "--frames", "3", "--orbit", "10", "--mode-at", "2:3",
+                        "--out", str(tmp_path / "three"), "--ranks", "3", "--host-exchange", "--same-device"], capture_output=True, text=True, timeout=300)
+    d = subprocess.run([exe, scene_file, "--mode", "100", "--size", "333x217", "--frames", "3", "--orbit", "10", "--mode-at", "2:3",
+                        "--out", str(tmp_path / "solo")], capture_output=True, text=True, timeout=300)
+    assert c.returncode == 0 and d.returncode == 0, c.stdout + c.stderr + d.stderr
+    assert "rank 0's tile share of 3 ranks" in c.stdout
+    for f in range(3):
+        np.testing.assert_array_equal(_read_ppm(str(tmp_path / ("three_%d.ppm" % f)), 333, 217), _read_ppm(str(tmp_path / ("solo_%d.ppm" % f)), 333, 217))
+    assert not [n for n in os.listdir("/dev/shm") if n.startswith("crt_render_")], "the exchange's shared memory was left behind"
 
 
 def test_reference_scene_layer_bound_to_the_c_abi(pkg, oracle, scenes, dragon, tmp_path, golden_dir):
