@@ -59,6 +59,7 @@ def test_comm_entry_points_reject_bad_arguments_without_a_gpu(pkg):
     L = pkg.lib()
     assert L.crt_comm_unique_id(None) == 1          # CRT_EINVAL
     assert L.crt_comm_init(None, 0, 1, None) == 1
+    assert L.crt_comm_init_host(None, 0, 1, b"/crt_test") == 1
     assert L.crt_comm_destroy(None) == 1
     assert L.crt_comm_info(None, None, None) == 1
     assert L.crt_render_frame_distributed(None, 64, 64, None, None, None) == 1
