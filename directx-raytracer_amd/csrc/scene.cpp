@@ -213,11 +213,20 @@ Vector TextureDesc::getColor(float u, float v) const
 
 void TextureDesc::loadBitmap(const std::string& sceneDir)
 {
+    // the path as the scene gives it (the reference hands it to stbi_load unchanged, R/CRTSceneParser.cpp:294-302), then relative to
+    // the scene file; a scene written on the reference's platform may spell it with backslashes: tried with '/' for '\\' last
     std::ifstream in(filePath, std::ios::binary);
     if (!in && !sceneDir.empty()) in.open(sceneDir + "/" + filePath, std::ios::binary);
+    if (!in && filePath.find('\\') != std::string::npos) {
+        std::string portable = filePath;
+        for (char& ch : portable)
+            if (ch == '\\') ch = '/';
+        in.open(portable, std::ios::binary);
+        if (!in && !sceneDir.empty()) in.open(sceneDir + "/" + portable, std::ios::binary);
+    }
     if (!in) throw std::runtime_error("cannot open texture file '" + filePath + "'");
     std::vector<unsigned char> file((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
-    DecodedImage img = decodeImage(file, filePath); // PNG / BMP / TGA / binary PPM, PGM: image_decode.cpp
+    DecodedImage img = decodeImage(file, filePath); // every format the reference's loader reads: image_decode.cpp, jpeg_decode.cpp
     width = img.width;
     height = img.height;
     fileChannels = img.channels;

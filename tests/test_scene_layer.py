@@ -353,7 +353,13 @@ def test_textured_scene_file(pkg, tmp_path, golden_dir):
     assert b.texture_count == 4 and b.materials()[0]["texture"] == 2
     np.testing.assert_array_equal(b.texture_color(3, 0.5, 0.5), s.texture_color(3, 0.5, 0.5))
     np.testing.assert_array_equal(b.mesh(0)["uvs"], s.mesh(0)["uvs"])
-    # a bitmap that is not a binary PPM/PGM is a load error, not a crash (the reference never checks stbi_load's result)
+    # a scene written on the reference's platform may spell the path with backslashes: found with '/' in their place
+    (tmp_path / "textures").mkdir()
+    shutil.copy(os.path.join(golden_dir, "tex_444.jpg"), tmp_path / "textures" / "wood.jpg")
+    q = tmp_path / "win.crtscene"
+    q.write_text(json.dumps({"objects": [], "materials": [], "textures": [{"name": "pic", "type": "bitmap", "file_path": "textures\\wood.jpg"}]}))
+    assert np.all(pkg.Scene(str(q)).texture_color(0, 0.5, 0.5) >= 0)
+    # a damaged bitmap is a load error, not a crash (the reference never checks stbi_load's result)
     (tmp_path / "img.ppm").write_bytes(b"\\x89PNG....")
     with pytest.raises(pkg.CrtError) as e:
         pkg.Scene(str(p))
