@@ -529,6 +529,41 @@ def main():
         extras["ms_per_frame_incl_d2h"], extras["ms_per_frame_incl_d2h_pinned"] = d2h[False], d2h[True]
         r.set_stream(main_stream.cuda_stream)
 
+    if not args.no_extras and not multi and not path:
+        # What a rank of an N-GPU job would have to do, measured on this one GPU: rank 0's share of the frame (1/N of the tiles, split
+        # packets at their multi-rank default) under the pipelining policy `value` uses at that N, the de-interleave of a gathered
+        # buffer of the right size included, the collective itself not.  An estimate of what the partition leaves per rank, labelled as such.
+        emu = {}
+        for n in (2, 4, 8):
+            e_fly, e_batch = default_policy(n, True, False)
+            sh = host.rank_share(W, H, 0, n)
+            e_per = sh["slots"] * 256
+            e_streams = [torch.cuda.Stream() for _ in range(e_fly)]
+            e_stage = [torch.zeros(e_batch * e_per, dtype=torch.int32, device="cuda") for _ in range(e_fly)]
+            e_gath = [torch.zeros(n * e_batch * e_per, dtype=torch.int32, device="cuda") for _ in range(e_fly)]
+            e_out = [torch.zeros(W * H, dtype=torch.int32, device="cuda") for _ in range(e_fly)]
+            torch.cuda.synchronize()
+
+            def launch(k):
+                st = e_streams[k % e_fly]
+                r.set_stream(st.cuda_stream)
+                r.render_tiles_batch_device(W, H, 0, n, [e_stage[k % e_fly].data_ptr() + 4 * e_per * f for f in range(e_batch)])
+                for f in range(e_batch):
+                    r.untile_batch_device(W, H, n, e_batch, f, e_gath[k % e_fly].data_ptr(), e_out[k % e_fly].data_ptr())
+            for k in range(24):
+                launch(k)
+            torch.cuda.synchronize()
+            launches = max(8, 200 // e_batch)
+            t0 = time.perf_counter()
+            for k in range(launches):
+                launch(k)
+            torch.cuda.synchronize()
+            emu[str(n)] = (time.perf_counter() - t0) / (launches * e_batch) * 1e3
+        r.set_stream(main_stream.cuda_stream)
+        extras["emulated_rank_share"] = {
+            "ms_per_frame": emu, "note": "ONE GPU doing rank 0's share of an N-rank frame (tiles + de-interleave, no collective) under the N > 1 "
+            "pipelining policy: what the tile partition leaves per rank, not a multi-GPU measurement"}
+
     ok = True
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -552,6 +587,8 @@ def main():
             "stream_ms_per_step": stream_ms / args.steps,
         }
         line.update(extras)
+        if "emulated_rank_share" in extras:
+            extras["emulated_rank_share"]["speedup_bound_vs_this_run"] = {n: ms_per_step / v for n, v in extras["emulated_rank_share"]["ms_per_frame"].items()}
         if args.same_device:
             line["rehearsal"] = "every rank on GPU 0, tiles exchanged through host memory over gloo: exercises the rank logic, measures nothing"
         if not multi:
