@@ -641,6 +641,10 @@ class Renderer:
         self._ok(lib().crt_comm_init(self.h, rank, n_ranks, C.create_string_buffer(unique_id, 128)), "crt_comm_init")
         return unique_id
 
+    def comm_init_host(self, rank, n_ranks, name):
+        """the same frame assembly with a POSIX shared-memory object ("/name") as the transport: ranks that share one GPU (rehearsal)"""
+        self._ok(lib().crt_comm_init_host(self.h, rank, n_ranks, name.encode()), "crt_comm_init_host")
+
     def comm_destroy(self):
         self._ok(lib().crt_comm_destroy(self.h), "crt_comm_destroy")
 

@@ -804,6 +804,15 @@ def test_native_rccl_gather_behind_the_c_abi(pkg, oracle, scenes, dragon, render
         np.testing.assert_array_equal(dev.cpu().numpy().view(np.uint8).reshape(77, 333, 4), r2.render_frame(333, 77, want=())["rgba8"])
         r2.comm_destroy()
         r2.comm_destroy()  # idempotent
+        # the host-memory transport behind the same calls (one rank: its own slice goes in and comes out)
+        r2.comm_init_host(0, 1, "/crt_test_%d" % os.getpid())
+        with pytest.raises(pkg.CrtError):
+            r2.comm_init_host(0, 1, "/crt_test_again_%d" % os.getpid())  # already has one
+        np.testing.assert_array_equal(r2.render_frame_distributed(w, h, host=True)["rgba8"], single)
+        r2.comm_destroy()
+        assert not [n for n in os.listdir("/dev/shm") if n.startswith("crt_test_")]
+        with pytest.raises(pkg.CrtError):
+            r2.comm_init_host(0, 1, "no_leading_slash")
     finally:
         r2.close()
     exe = os.path.join(os.path.dirname(pkg.LIB_PATH), "crt_render")
