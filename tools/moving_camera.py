@@ -25,6 +25,10 @@ def main():
         c, s = np.cos(a), np.sin(a)
         R = np.float32([[c, 0, s], [0, 1, 0], [-s, 0, c]])
         return (R @ pos0).astype(np.float32), (R @ np.float32(sc["camera"]["matrix"]).reshape(3, 3)).astype(np.float32).reshape(9)
+    wobble = "--wobble" in sys.argv  # the camera swings +-0.005 degrees about the static view instead of travelling along an orbit: same picture
+    if wobble:
+        orbit = cam
+        cam = lambda i: orbit(130 + 0.5 * (1 if i % 2 else -1))
     for moving, every in ((False, 1), (False, -1), (True, 1), (True, 2), (True, 8), (True, 32), (False, 1)):
         if every < 0 and not have_diag: continue
         if have_diag: r.set_option("debug_force_measure", 1 if every < 0 else 0)  # -1: static view, but measured and sorted at every frame
