@@ -409,8 +409,9 @@ int runRender(crt_ctx* c, RenderParams& p, crt_frame_stats* stats)
         // Costs are measured (and sorted) twice in a row -- the first measurement ran under an unordered launch -- and then:
         // an unchanged view keeps its order for good; a view that keeps changing (a moving camera) measures again every
         // remeasure_every-th use of the slot.  Default 1: the order ages fast -- with a camera turning 0.01 degrees per frame
-        // an order 32 frames old cost 0.367 ms per frame, 128 frames old 0.423, against 0.347 when measured every frame
-        // (0.323 for a static view: cost stores and the sort beside the next frame are the 7 % difference).
+        // an order 32 frames old cost 0.367 ms per frame, 128 frames old 0.423, against 0.347 when measured every frame.
+        // (The feedback itself -- cost stores, the sort beside the next frame -- is 1.4 % of a frame: tools/moving_camera.py --wobble;
+        //  the rest of that run's difference to a static view was the frame's own cost changing along the orbit.)
         const bool twice = usable && c->orderGen[slot] >= 2;
         const bool sameView = c->orderView[slot] == c->viewSerial;
         const bool recent = (c->frameSerial - c->orderFrame[slot]) < static_cast<uint32_t>(crt_ctx::kRing) * c->tuneRemeasureEvery;
